@@ -1,0 +1,139 @@
+// Handle lifetime, error reporting, HIP-event timers and HIP-graph capture for liblipasr.
+#include "common.h"
+
+namespace lipasr {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+void mfcc_plan_free(MfccPlan* p);  // mfcc.hip
+
+}  // namespace lipasr
+
+using namespace lipasr;
+
+extern "C" {
+
+int lipasr_version(void) { return 200; }  // round 2
+
+const char* lipasr_last_error(void) { return g_err; }
+
+int lipasr_create(int device, lipasr_handle_t* out) {
+  LP_CHECK_ARG(out != nullptr, "lipasr_create: out is null");
+  int n = 0;
+  LP_HIP(hipGetDeviceCount(&n));
+  LP_CHECK_ARG(device >= 0 && device < n, "lipasr_create: device %d out of range (have %d)", device, n);
+  hipDeviceProp_t prop;
+  LP_HIP(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    set_error("lipasr_create: device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+    return LIPASR_EUNSUPPORTED;
+  }
+  DeviceGuard g(device);
+  if (!g.ok) { set_error("lipasr_create: hipSetDevice(%d) failed", device); return LIPASR_EHIP; }
+  lipasr_ctx* c = new lipasr_ctx();
+  c->device = device;
+  c->scratch_floats = kScratchFloats;
+  if (hipMalloc(&c->scratch, c->scratch_floats * sizeof(float)) != hipSuccess) {
+    delete c;
+    set_error("lipasr_create: scratch allocation failed");
+    return LIPASR_ENOMEM;
+  }
+  if (hipMemset(c->scratch, 0, c->scratch_floats * sizeof(float)) != hipSuccess) {
+    (void)hipFree(c->scratch);
+    delete c;
+    set_error("lipasr_create: scratch memset failed");
+    return LIPASR_EHIP;
+  }
+  *out = c;
+  return LIPASR_OK;
+}
+
+int lipasr_destroy(lipasr_handle_t h) {
+  LP_CHECK_ARG(h != nullptr, "lipasr_destroy: null handle");
+  DeviceGuard g(h->device);
+  for (hipEvent_t e : h->timers) (void)hipEventDestroy(e);
+  for (hipGraphExec_t ge : h->graphs)
+    if (ge) (void)hipGraphExecDestroy(ge);
+  if (h->mfcc) mfcc_plan_free(h->mfcc);
+  if (h->scratch) (void)hipFree(h->scratch);
+  delete h;
+  return LIPASR_OK;
+}
+
+// ------------------------------------------------------------------ timers
+int lipasr_timer_create(lipasr_handle_t h, int* timer_id) {
+  LP_CHECK_ARG(h && timer_id, "lipasr_timer_create: null argument");
+  DeviceGuard g(h->device);
+  hipEvent_t a, b;
+  LP_HIP(hipEventCreate(&a));
+  LP_HIP(hipEventCreate(&b));
+  *timer_id = (int)(h->timers.size() / 2);
+  h->timers.push_back(a);
+  h->timers.push_back(b);
+  return LIPASR_OK;
+}
+
+int lipasr_timer_start(lipasr_handle_t h, int id, lipasr_stream_t stream) {
+  LP_CHECK_ARG(h && id >= 0 && (size_t)(2 * id + 1) < h->timers.size(), "lipasr_timer_start: bad timer id %d", id);
+  LP_HIP(hipEventRecord(h->timers[2 * id], S(stream)));
+  return LIPASR_OK;
+}
+
+int lipasr_timer_stop(lipasr_handle_t h, int id, lipasr_stream_t stream) {
+  LP_CHECK_ARG(h && id >= 0 && (size_t)(2 * id + 1) < h->timers.size(), "lipasr_timer_stop: bad timer id %d", id);
+  LP_HIP(hipEventRecord(h->timers[2 * id + 1], S(stream)));
+  return LIPASR_OK;
+}
+
+int lipasr_timer_elapsed_ms(lipasr_handle_t h, int id, float* ms_host) {
+  LP_CHECK_ARG(h && ms_host && id >= 0 && (size_t)(2 * id + 1) < h->timers.size(),
+               "lipasr_timer_elapsed_ms: bad argument");
+  LP_HIP(hipEventSynchronize(h->timers[2 * id + 1]));
+  LP_HIP(hipEventElapsedTime(ms_host, h->timers[2 * id], h->timers[2 * id + 1]));
+  return LIPASR_OK;
+}
+
+// ------------------------------------------------------------------ graphs
+int lipasr_graph_begin(lipasr_handle_t h, lipasr_stream_t stream) {
+  LP_CHECK_ARG(h != nullptr, "lipasr_graph_begin: null handle");
+  LP_HIP(hipStreamBeginCapture(S(stream), hipStreamCaptureModeThreadLocal));
+  return LIPASR_OK;
+}
+
+int lipasr_graph_end(lipasr_handle_t h, lipasr_stream_t stream, int* graph_id) {
+  LP_CHECK_ARG(h && graph_id, "lipasr_graph_end: null argument");
+  hipGraph_t graph = nullptr;
+  LP_HIP(hipStreamEndCapture(S(stream), &graph));
+  hipGraphExec_t exec = nullptr;
+  hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (e != hipSuccess) {
+    set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e));
+    return LIPASR_EHIP;
+  }
+  *graph_id = (int)h->graphs.size();
+  h->graphs.push_back(exec);
+  return LIPASR_OK;
+}
+
+int lipasr_graph_launch(lipasr_handle_t h, int id, lipasr_stream_t stream) {
+  LP_CHECK_ARG(h && id >= 0 && (size_t)id < h->graphs.size() && h->graphs[id], "lipasr_graph_launch: bad graph id %d", id);
+  LP_HIP(hipGraphLaunch(h->graphs[id], S(stream)));
+  return LIPASR_OK;
+}
+
+int lipasr_graph_destroy(lipasr_handle_t h, int id) {
+  LP_CHECK_ARG(h && id >= 0 && (size_t)id < h->graphs.size() && h->graphs[id], "lipasr_graph_destroy: bad graph id %d", id);
+  LP_HIP(hipGraphExecDestroy(h->graphs[id]));
+  h->graphs[id] = nullptr;
+  return LIPASR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,740 @@
+// K2: the dense classifier on fp32 MFMA (gfx950), plus BatchNorm / dropout / softmax-CE kernels and
+// the plan-level forward / backward / predict / attack sequences.
+//
+// GEMM design (v_mfma_f32_32x32x2_f32, exact fp32 fma chains):
+//   The classifier's GEMMs are small (M = batch 512..1024, N <= 1024, K <= 1024): with one 32x32
+//   accumulator per wavefront the time of a tile is (K/2) MFMAs * 64 cycles whatever M and N are,
+//   so the lever is K, not the tile.  One workgroup = one 32x32 output tile, its 4 wavefronts split
+//   K four ways (16-deep chunks, round-robin), operands go straight from global/L2 to VGPRs in MFMA
+//   layout (no LDS staging, no barrier in the main loop, next chunk prefetched behind the MFMAs),
+//   the four partial tiles meet in LDS once and 256 threads run the fused epilogue with float4
+//   stores.  K order inside a chunk is permuted (lane half h takes k0+8h..k0+8h+7) so that
+//   K-contiguous operands load as two float4 per lane; both operands use the same permutation.
+//
+//   Epilogues fuse: bias (+ReLU), inference BatchNorm affine, the ReLU/BN backward mask of the
+//   inference-mode input gradient, and the FGSM/PGD sign step (K4) on the last backward GEMM.
+#include "mlp.h"
+
+namespace lipasr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum Epi { EPI_STORE = 0, EPI_BIAS = 1, EPI_BIAS_RELU = 2, EPI_BIAS_RELU_BN = 3, EPI_DZ_INFER = 4, EPI_SIGNSTEP = 5 };
+
+struct GemmArgs {
+  const float* A;
+  const float* B;
+  float* C;
+  int M, N, K, lda, ldb, ldc;
+  int epi;
+  const float* bias;
+  const float* gamma;
+  const float* beta;
+  const float* mmean;
+  const float* mvar;
+  float* aux;        // EPI_BIAS_RELU_BN: optional post-ReLU store; EPI_DZ_INFER: post-ReLU activations (read)
+  const float* x0;   // EPI_SIGNSTEP
+  float* x_adv;
+  float alpha, eps;
+};
+
+// AMODE/BMODE 0: K contiguous in memory (operand(i,k) = P[i*ld + k]); 1: K strided (P[k*ld + i]).
+template <int MODE>
+__device__ __forceinline__ void load_frag(const float* __restrict__ P, int ld, int idx, int kb, int K, bool vec,
+                                          float (&f)[8]) {
+  if (MODE == 0) {
+    const float* p = P + (size_t)idx * ld + kb;
+    if (vec && kb + 8 <= K) {
+      const float4 lo = *reinterpret_cast<const float4*>(p);
+      const float4 hi = *reinterpret_cast<const float4*>(p + 4);
+      f[0] = lo.x; f[1] = lo.y; f[2] = lo.z; f[3] = lo.w;
+      f[4] = hi.x; f[5] = hi.y; f[6] = hi.z; f[7] = hi.w;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) f[q] = (kb + q < K) ? p[q] : 0.0f;
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) f[q] = (kb + q < K) ? P[(size_t)(kb + q) * ld + idx] : 0.0f;
+  }
+}
+
+__device__ __forceinline__ float epilogue_elem(const GemmArgs& g, int gm, int gn, float v) {
+  switch (g.epi) {
+    case EPI_BIAS:
+      return v + g.bias[gn];
+    case EPI_BIAS_RELU:
+      return fmaxf(v + g.bias[gn], 0.0f);
+    case EPI_BIAS_RELU_BN: {
+      const float a = fmaxf(v + g.bias[gn], 0.0f);
+      if (g.aux) g.aux[(size_t)gm * g.ldc + gn] = a;
+      if (g.gamma) return (a - g.mmean[gn]) / sqrtf(g.mvar[gn] + kBnEps) * g.gamma[gn] + g.beta[gn];
+      return a;
+    }
+    case EPI_DZ_INFER: {
+      const float s = g.gamma ? g.gamma[gn] / sqrtf(g.mvar[gn] + kBnEps) : 1.0f;
+      return g.aux[(size_t)gm * g.ldc + gn] > 0.0f ? v * s : 0.0f;
+    }
+    case EPI_SIGNSTEP: {
+      const size_t i = (size_t)gm * g.ldc + gn;
+      const float sg = (v > 0.0f) ? 1.0f : ((v < 0.0f) ? -1.0f : 0.0f);  // NaN -> 0, as ART zeroes NaN gradients
+      const float x0 = g.x0[i];
+      const float xa = g.x_adv[i] + g.alpha * sg;
+      if (isinf(g.eps)) return xa;
+      return x0 + fminf(fmaxf(xa - x0, -g.eps), g.eps);
+    }
+    default:
+      return v;
+  }
+}
+
+template <int AMODE, int BMODE>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float red[4 * 32 * 32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+  const int ai = min(m0 + r, g.M - 1);
+  const int bj = min(n0 + r, g.N - 1);
+  const int nch = (g.K + 15) >> 4;
+  const bool vecA = (AMODE == 0) && ((g.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0);
+  const bool vecB = (BMODE == 0) && ((g.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0);
+
+  f32x16 acc;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+  float a0[8], b0[8], a1[8], b1[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { a0[q] = b0[q] = a1[q] = b1[q] = 0.0f; }
+
+  int c = wave;
+  if (c < nch) {
+    load_frag<AMODE>(g.A, g.lda, ai, c * 16 + 8 * h, g.K, vecA, a0);
+    load_frag<BMODE>(g.B, g.ldb, bj, c * 16 + 8 * h, g.K, vecB, b0);
+  }
+  while (c < nch) {
+    const int cn = c + 4;
+    if (cn < nch) {
+      load_frag<AMODE>(g.A, g.lda, ai, cn * 16 + 8 * h, g.K, vecA, a1);
+      load_frag<BMODE>(g.B, g.ldb, bj, cn * 16 + 8 * h, g.K, vecB, b1);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q], b0[q], acc, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { a0[q] = a1[q]; b0[q] = b1[q]; }
+    c = cn;
+  }
+  // C/D map: col = lane & 31, row = (q & 3) + 8 (q >> 2) + 4 (lane >> 5)
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int row = (q & 3) + 8 * (q >> 2) + 4 * h;
+    red[wave * 1024 + row * 32 + r] = acc[q];
+  }
+  __syncthreads();
+  const int row = tid >> 3, c4 = (tid & 7) * 4;
+  float4 s = *reinterpret_cast<const float4*>(red + row * 32 + c4);
+#pragma unroll
+  for (int w = 1; w < 4; ++w) {
+    const float4 t = *reinterpret_cast<const float4*>(red + w * 1024 + row * 32 + c4);
+    s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+  }
+  const int gm = m0 + row;
+  if (gm >= g.M) return;
+  const int gn = n0 + c4;
+  float* crow = (g.epi == EPI_SIGNSTEP ? g.x_adv : g.C) + (size_t)gm * g.ldc;
+  if (gn + 3 < g.N && ((g.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(crow) & 15) == 0)) {
+    float4 o;
+    o.x = epilogue_elem(g, gm, gn, s.x);
+    o.y = epilogue_elem(g, gm, gn + 1, s.y);
+    o.z = epilogue_elem(g, gm, gn + 2, s.z);
+    o.w = epilogue_elem(g, gm, gn + 3, s.w);
+    *reinterpret_cast<float4*>(crow + gn) = o;
+  } else {
+    const float v[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (gn + e < g.N) crow[gn + e] = epilogue_elem(g, gm, gn + e, v[e]);
+  }
+}
+
+static int launch_gemm(int amode, int bmode, const GemmArgs& g, hipStream_t st) {
+  if (g.M <= 0 || g.N <= 0 || g.K <= 0) {
+    set_error("gemm: empty problem %dx%dx%d", g.M, g.N, g.K);
+    return LIPASR_EINVAL;
+  }
+  const dim3 grid((g.N + 31) / 32, (g.M + 31) / 32);
+  if (amode == 0 && bmode == 0) hipLaunchKernelGGL((gemm_f32_kernel<0, 0>), grid, dim3(256), 0, st, g);
+  else if (amode == 0 && bmode == 1) hipLaunchKernelGGL((gemm_f32_kernel<0, 1>), grid, dim3(256), 0, st, g);
+  else if (amode == 1 && bmode == 0) hipLaunchKernelGGL((gemm_f32_kernel<1, 0>), grid, dim3(256), 0, st, g);
+  else hipLaunchKernelGGL((gemm_f32_kernel<1, 1>), grid, dim3(256), 0, st, g);
+  LP_LAUNCH_CHECK();
+  return LIPASR_OK;
+}
+
+static GemmArgs gemm_args(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
+                          int epi) {
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.epi = epi;
+  return g;
+}
+
+// ---------------------------------------------------------------------------------------------
+// dropout multiplier: 0 or 1/(1-rate), Philox keyed by (seed; element/4, layer, step)
+// ---------------------------------------------------------------------------------------------
+struct DropArgs {
+  int mode;  // 0 off, 1 philox, 2 external
+  float rate;
+  uint64_t seed;
+  const int* step_dev;
+  int layer;
+  const float* mask;
+};
+
+__device__ __forceinline__ float dropout_mult(const DropArgs& d, int step, size_t e) {
+  if (d.mode == 0 || d.rate <= 0.0f) return 1.0f;
+  if (d.mode == 2) return d.mask ? d.mask[e] : 1.0f;
+  uint32_t o[4];
+  Philox::gen(d.seed, (uint64_t)(e >> 2), (uint32_t)d.layer, (uint32_t)step, o);
+  const float u = Philox::u01(o[e & 3]);
+  return u > d.rate ? 1.0f / (1.0f - d.rate) : 0.0f;
+}
+
+// column-block helpers: 256 threads = 32 columns x 8 row lanes
+__device__ __forceinline__ float colblock_sum(float x, float (*part)[33], int cx, int ry) {
+  __syncthreads();
+  part[ry][cx] = x;
+  __syncthreads();
+  return ((part[0][cx] + part[1][cx]) + (part[2][cx] + part[3][cx])) +
+         ((part[4][cx] + part[5][cx]) + (part[6][cx] + part[7][cx]));
+}
+
+struct BnFwdArgs {
+  const float* a;  // [B][N] post-ReLU
+  float* h;        // [B][N] out
+  int B, N, has_bn;
+  const float* gamma;
+  const float* beta;
+  float* mmean;
+  float* mvar;
+  float* save_mean;  // [N], rstd at save_mean + N
+  DropArgs drop;
+};
+
+// training-mode BatchNorm (batch statistics, population variance, two-pass) + inverted dropout.
+// One workgroup owns 32 columns and all B rows, so the statistics need no cross-workgroup step.
+__global__ __launch_bounds__(256) void bn_fwd_train_kernel(BnFwdArgs p) {
+  __shared__ float part[8][33];
+  const int tid = threadIdx.x, cx = tid & 31, ry = tid >> 5;
+  const int j = blockIdx.x * 32 + cx;
+  const bool live = j < p.N;
+  const int step = p.drop.step_dev ? *p.drop.step_dev : 0;
+  float mean = 0.0f, rstd = 1.0f, ga = 1.0f, be = 0.0f;
+  if (p.has_bn) {
+    float s = 0.0f;
+    if (live)
+      for (int b = ry; b < p.B; b += 8) s += p.a[(size_t)b * p.N + j];
+    mean = colblock_sum(s, part, cx, ry) / (float)p.B;
+    float q = 0.0f;
+    if (live)
+      for (int b = ry; b < p.B; b += 8) {
+        const float d = p.a[(size_t)b * p.N + j] - mean;
+        q = fmaf(d, d, q);
+      }
+    const float var = colblock_sum(q, part, cx, ry) / (float)p.B;
+    rstd = 1.0f / sqrtf(var + kBnEps);
+    if (live) {
+      ga = p.gamma[j];
+      be = p.beta[j];
+      if (ry == 0) {
+        p.save_mean[j] = mean;
+        p.save_mean[p.N + j] = rstd;
+        p.mmean[j] = p.mmean[j] * kBnMomentum + mean * (1.0f - kBnMomentum);
+        p.mvar[j] = p.mvar[j] * kBnMomentum + var * (1.0f - kBnMomentum);
+      }
+    }
+  }
+  if (!live) return;
+  for (int b = ry; b < p.B; b += 8) {
+    const size_t e = (size_t)b * p.N + j;
+    float x = p.a[e];
+    if (p.has_bn) x = (x - mean) * rstd * ga + be;
+    p.h[e] = x * dropout_mult(p.drop, step, e);
+  }
+}
+
+struct BnBwdArgs {
+  const float* dh;  // [B][N] gradient w.r.t. the layer's output (after BN and dropout)
+  const float* a;   // [B][N] post-ReLU
+  float* dz;        // [B][N] gradient w.r.t. the pre-activation
+  int B, N, has_bn;
+  const float* gamma;
+  const float* save_mean;
+  float* dgamma;
+  float* dbeta;
+  float* db;
+  DropArgs drop;
+};
+
+// backward of Dropout -> BatchNorm(train) -> ReLU in one kernel; also the bias gradient (column sum of dz)
+__global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs p) {
+  __shared__ float part[8][33];
+  const int tid = threadIdx.x, cx = tid & 31, ry = tid >> 5;
+  const int j = blockIdx.x * 32 + cx;
+  const bool live = j < p.N;
+  const int step = p.drop.step_dev ? *p.drop.step_dev : 0;
+  float mean = 0.0f, rstd = 1.0f, ga = 1.0f, dg = 0.0f, dbt = 0.0f;
+  if (p.has_bn) {
+    if (live) {
+      mean = p.save_mean[j];
+      rstd = p.save_mean[p.N + j];
+      ga = p.gamma[j];
+    }
+    float s1 = 0.0f, s2 = 0.0f;
+    if (live)
+      for (int b = ry; b < p.B; b += 8) {
+        const size_t e = (size_t)b * p.N + j;
+        const float g = p.dh[e] * dropout_mult(p.drop, step, e);
+        const float xh = (p.a[e] - mean) * rstd;
+        s1 = fmaf(g, xh, s1);
+        s2 += g;
+      }
+    dg = colblock_sum(s1, part, cx, ry);
+    dbt = colblock_sum(s2, part, cx, ry);
+    if (live && ry == 0) {
+      p.dgamma[j] = dg;
+      p.dbeta[j] = dbt;
+    }
+  }
+  const float invB = 1.0f / (float)p.B;
+  float sb = 0.0f;
+  if (live)
+    for (int b = ry; b < p.B; b += 8) {
+      const size_t e = (size_t)b * p.N + j;
+      const float av = p.a[e];
+      float g = p.dh[e] * dropout_mult(p.drop, step, e);
+      if (p.has_bn) {
+        const float xh = (av - mean) * rstd;
+        g = ga * rstd * (g - dbt * invB - xh * dg * invB);
+      }
+      g = av > 0.0f ? g : 0.0f;
+      p.dz[e] = g;
+      sb += g;
+    }
+  const float dbias = colblock_sum(sb, part, cx, ry);
+  if (live && ry == 0) p.db[j] = dbias;
+}
+
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int B, int N, float* __restrict__ out) {
+  __shared__ float part[8][33];
+  const int tid = threadIdx.x, cx = tid & 31, ry = tid >> 5;
+  const int j = blockIdx.x * 32 + cx;
+  float s = 0.0f;
+  if (j < N)
+    for (int b = ry; b < B; b += 8) s += x[(size_t)b * N + j];
+  const float t = colblock_sum(s, part, cx, ry);
+  if (j < N && ry == 0) out[j] = t;
+}
+
+// softmax + categorical cross-entropy from logits, one thread per row.
+//   prob (optional), dz = (p - y) * inv_batch (optional), loss_rows = -sum y log_softmax(z) (optional),
+//   correct_rows = [argmax p == argmax y] (optional), onehot_out = one-hot argmax z (optional)
+__global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict__ z, const float* __restrict__ y, int B,
+                                                          int C, float inv_batch, float* __restrict__ prob,
+                                                          float* __restrict__ dz, float* __restrict__ loss_rows,
+                                                          float* __restrict__ correct_rows,
+                                                          float* __restrict__ onehot_out) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  const float* zr = z + (size_t)b * C;
+  float mx = zr[0];
+  int am = 0;
+  for (int c = 1; c < C; ++c)
+    if (zr[c] > mx) { mx = zr[c]; am = c; }
+  float se = 0.0f;
+  for (int c = 0; c < C; ++c) se += expf(zr[c] - mx);
+  const float lse = logf(se);
+  const float inv = 1.0f / se;
+  float loss = 0.0f, ymax = -INFINITY;
+  int ay = 0;
+  for (int c = 0; c < C; ++c) {
+    const float zs = zr[c] - mx;
+    const float pc = expf(zs) * inv;
+    if (prob) prob[(size_t)b * C + c] = pc;
+    if (y) {
+      const float yc = y[(size_t)b * C + c];
+      if (yc != 0.0f) loss -= yc * (zs - lse);
+      if (yc > ymax) { ymax = yc; ay = c; }
+      if (dz) dz[(size_t)b * C + c] = (pc - yc) * inv_batch;
+    }
+    if (onehot_out) onehot_out[(size_t)b * C + c] = (c == am) ? 1.0f : 0.0f;
+  }
+  if (loss_rows) loss_rows[b] = loss;
+  if (correct_rows) correct_rows[b] = (am == ay) ? 1.0f : 0.0f;
+}
+
+static inline size_t align4(size_t x) { return (x + 3) & ~size_t(3); }
+
+}  // namespace lipasr
+
+using namespace lipasr;
+
+// ------------------------------------------------------------------------------------------------
+// plan
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+int lipasr_gemm_f32(lipasr_handle_t h, int transA, int transB, int M, int N, int K, const float* A, int lda,
+                    const float* B, int ldb, float* C, int ldc, lipasr_stream_t stream) {
+  LP_CHECK_ARG(h && A && B && C, "lipasr_gemm_f32: null argument");
+  LP_CHECK_ARG(M > 0 && N > 0 && K > 0, "lipasr_gemm_f32: empty problem %dx%dx%d", M, N, K);
+  LP_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, "lipasr_gemm_f32: leading dimension too small");
+  GemmArgs g = gemm_args(A, lda, B, ldb, C, ldc, M, N, K, EPI_STORE);
+  return launch_gemm(transA ? 1 : 0, transB ? 0 : 1, g, S(stream));
+}
+
+int lipasr_mlp_create(lipasr_handle_t h, int n_layers, const int* widths, const int* bn, const float* dropout,
+                      const int* nonneg, int max_batch, lipasr_mlp_t* out) {
+  LP_CHECK_ARG(h && widths && out, "lipasr_mlp_create: null argument");
+  LP_CHECK_ARG(n_layers >= 1 && n_layers <= LIPASR_MAX_LAYERS, "lipasr_mlp_create: n_layers=%d outside [1,%d]", n_layers,
+               LIPASR_MAX_LAYERS);
+  LP_CHECK_ARG(max_batch >= 1, "lipasr_mlp_create: max_batch=%d", max_batch);
+  for (int l = 0; l <= n_layers; ++l) LP_CHECK_ARG(widths[l] >= 1, "lipasr_mlp_create: widths[%d]=%d", l, widths[l]);
+  LP_CHECK_ARG(widths[n_layers] <= 32, "lipasr_mlp_create: %d classes; at most 32 are supported", widths[n_layers]);
+  lipasr_mlp* m = new lipasr_mlp();
+  m->ctx = h;
+  m->n_layers = n_layers;
+  m->max_batch = max_batch;
+  size_t po = 0, so = 0, wo = 0;
+  int maxw = widths[0];
+  for (int l = 0; l < n_layers; ++l) {
+    MlpLayer& L = m->L[l];
+    L.n_in = widths[l];
+    L.n_out = widths[l + 1];
+    const bool last = (l == n_layers - 1);
+    L.bn = !last && bn && bn[l];
+    L.dropout = (!last && dropout) ? dropout[l] : 0.0f;
+    L.nonneg = nonneg && nonneg[l];
+    if (L.dropout < 0.0f || L.dropout >= 1.0f) {
+      delete m;
+      set_error("lipasr_mlp_create: dropout[%d]=%g outside [0,1)", l, (double)L.dropout);
+      return LIPASR_EINVAL;
+    }
+    maxw = L.n_out > maxw ? L.n_out : maxw;
+    L.offW = po; po = align4(po + (size_t)L.n_in * L.n_out);
+    L.offb = po; po = align4(po + L.n_out);
+    if (L.bn) {
+      L.offg = po; po = align4(po + L.n_out);
+      L.offbe = po; po = align4(po + L.n_out);
+      L.offmm = so; so = align4(so + L.n_out);
+      L.offmv = so; so = align4(so + L.n_out);
+    }
+    if (!last) {
+      L.offA = wo; wo = align4(wo + (size_t)max_batch * L.n_out);
+      if (L.bn || L.dropout > 0.0f) { L.offH = wo; wo = align4(wo + (size_t)max_batch * L.n_out); }
+      else L.offH = L.offA;
+      L.offMean = wo; wo = align4(wo + 2 * (size_t)L.n_out);
+    }
+  }
+  m->n_params = po;
+  m->n_state = so;
+  m->max_width = maxw;
+  const size_t C = widths[n_layers];
+  m->offLogits = wo; wo = align4(wo + (size_t)max_batch * C);
+  m->offProb = wo; wo = align4(wo + (size_t)max_batch * C);
+  m->offDzLast = wo; wo = align4(wo + (size_t)max_batch * C);
+  m->offG0 = wo; wo = align4(wo + (size_t)max_batch * maxw);
+  m->offG1 = wo; wo = align4(wo + (size_t)max_batch * maxw);
+  m->offLossTmp = wo; wo = align4(wo + (size_t)max_batch * C);
+  m->ws_floats = wo;
+  DeviceGuard g(h->device);
+  if (hipMalloc(&m->ws, wo * sizeof(float)) != hipSuccess) {
+    delete m;
+    set_error("lipasr_mlp_create: workspace allocation of %zu bytes failed", wo * sizeof(float));
+    return LIPASR_ENOMEM;
+  }
+  (void)hipMemset(m->ws, 0, wo * sizeof(float));
+  *out = m;
+  return LIPASR_OK;
+}
+
+int lipasr_mlp_destroy(lipasr_mlp_t m) {
+  LP_CHECK_ARG(m != nullptr, "lipasr_mlp_destroy: null plan");
+  DeviceGuard g(m->ctx->device);
+  if (m->ws) (void)hipFree(m->ws);
+  delete m;
+  return LIPASR_OK;
+}
+
+int lipasr_mlp_sizes(lipasr_mlp_t m, size_t* n_params, size_t* n_state) {
+  LP_CHECK_ARG(m && n_params && n_state, "lipasr_mlp_sizes: null argument");
+  *n_params = m->n_params;
+  *n_state = m->n_state;
+  return LIPASR_OK;
+}
+
+int lipasr_mlp_segment(lipasr_mlp_t m, int layer, int kind, size_t* offset, size_t* count) {
+  LP_CHECK_ARG(m && offset && count, "lipasr_mlp_segment: null argument");
+  LP_CHECK_ARG(layer >= 0 && layer < m->n_layers, "lipasr_mlp_segment: layer %d out of range", layer);
+  const MlpLayer& L = m->L[layer];
+  switch (kind) {
+    case LIPASR_SEG_W: *offset = L.offW; *count = (size_t)L.n_in * L.n_out; break;
+    case LIPASR_SEG_B: *offset = L.offb; *count = L.n_out; break;
+    case LIPASR_SEG_GAMMA: *offset = L.offg; *count = L.bn ? L.n_out : 0; break;
+    case LIPASR_SEG_BETA: *offset = L.offbe; *count = L.bn ? L.n_out : 0; break;
+    case LIPASR_SEG_MMEAN: *offset = L.offmm; *count = L.bn ? L.n_out : 0; break;
+    case LIPASR_SEG_MVAR: *offset = L.offmv; *count = L.bn ? L.n_out : 0; break;
+    default: set_error("lipasr_mlp_segment: unknown kind %d", kind); return LIPASR_EINVAL;
+  }
+  return LIPASR_OK;
+}
+
+}  // extern "C"
+
+namespace lipasr {
+
+static int check_batch(const char* fn, lipasr_mlp_t m, int batch) {
+  LP_CHECK_ARG(m != nullptr, "%s: null plan", fn);
+  LP_CHECK_ARG(batch >= 1 && batch <= m->max_batch, "%s: batch %d outside [1, %d]", fn, batch, m->max_batch);
+  return LIPASR_OK;
+}
+
+static DropArgs drop_for_layer(const lipasr_mlp* m, int l, const lipasr_dropout_cfg* cfg) {
+  DropArgs d;
+  memset(&d, 0, sizeof(d));
+  d.rate = m->L[l].dropout;
+  d.layer = l;
+  if (!cfg || cfg->mode == 0 || d.rate <= 0.0f) { d.mode = 0; return d; }
+  d.mode = cfg->mode;
+  d.seed = cfg->seed;
+  d.step_dev = cfg->step_dev;
+  d.mask = (cfg->mode == 2 && cfg->masks) ? cfg->masks[l] : nullptr;
+  if (cfg->mode == 2 && d.mask == nullptr) d.mode = 0;
+  return d;
+}
+
+// inference-mode forward: fills A_l (post-ReLU, if keep_a) and H_l, logits into m->ws
+static int forward_infer(lipasr_mlp* m, const float* params, const float* bnstate, const float* x, int batch,
+                         bool keep_a, float* logits_out, hipStream_t st) {
+  const float* hin = x;
+  for (int l = 0; l < m->n_layers; ++l) {
+    const MlpLayer& L = m->L[l];
+    const bool last = (l == m->n_layers - 1);
+    float* outp = last ? logits_out : (m->ws + L.offH);
+    GemmArgs g = gemm_args(hin, L.n_in, params + L.offW, L.n_out, outp, L.n_out, batch, L.n_out, L.n_in,
+                           last ? EPI_BIAS : EPI_BIAS_RELU_BN);
+    g.bias = params + L.offb;
+    if (!last) {
+      if (L.bn) {
+        g.gamma = params + L.offg;
+        g.beta = params + L.offbe;
+        g.mmean = bnstate + L.offmm;
+        g.mvar = bnstate + L.offmv;
+      }
+      // when H aliases A (no BN, no dropout) the ReLU output lands in H == A directly
+      g.aux = (keep_a && L.offH != L.offA) ? (m->ws + L.offA) : nullptr;
+    }
+    int rc = launch_gemm(0, 1, g, st);
+    if (rc != LIPASR_OK) return rc;
+    hin = outp;
+  }
+  return LIPASR_OK;
+}
+
+// inference-mode backward to the input from dz at the logits (in m->ws + offDzLast).
+// final_mode 0: store dx; 1: fused sign step on x_adv.
+static int backward_infer(lipasr_mlp* m, const float* params, const float* bnstate, int batch, float* dx, float* x_adv,
+                          const float* x0, float alpha, float eps, hipStream_t st) {
+  const float* gin = m->ws + m->offDzLast;
+  float* pp[2] = {m->ws + m->offG0, m->ws + m->offG1};
+  int cur = 0;
+  for (int l = m->n_layers - 1; l >= 0; --l) {
+    const MlpLayer& L = m->L[l];
+    // dprev[B][n_in] = gin[B][n_out] * W^T ; W stored [n_in][n_out] -> K (= n_out) contiguous
+    if (l > 0) {
+      const MlpLayer& P = m->L[l - 1];
+      GemmArgs g = gemm_args(gin, L.n_out, params + L.offW, L.n_out, pp[cur], L.n_in, batch, L.n_in, L.n_out,
+                             EPI_DZ_INFER);
+      if (P.bn) {
+        g.gamma = params + P.offg;
+        g.mvar = bnstate + P.offmv;
+      }
+      g.aux = m->ws + P.offA;
+      int rc = launch_gemm(0, 0, g, st);
+      if (rc != LIPASR_OK) return rc;
+      gin = pp[cur];
+      cur ^= 1;
+    } else {
+      GemmArgs g = gemm_args(gin, L.n_out, params + L.offW, L.n_out, dx, L.n_in, batch, L.n_in, L.n_out,
+                             x_adv ? EPI_SIGNSTEP : EPI_STORE);
+      g.x_adv = x_adv;
+      g.x0 = x0;
+      g.alpha = alpha;
+      g.eps = eps;
+      int rc = launch_gemm(0, 0, g, st);
+      if (rc != LIPASR_OK) return rc;
+    }
+  }
+  return LIPASR_OK;
+}
+
+}  // namespace lipasr
+
+extern "C" {
+
+int lipasr_mlp_train_fwd_bwd(lipasr_mlp_t m, const float* params, float* bnstate, const float* x, const float* y_onehot,
+                             int batch, float inv_batch, const lipasr_dropout_cfg* dropout, float* grads,
+                             float* loss_rows, float* correct_rows, float* probs, lipasr_stream_t stream) {
+  int rc = check_batch("lipasr_mlp_train_fwd_bwd", m, batch);
+  if (rc != LIPASR_OK) return rc;
+  LP_CHECK_ARG(params && x && y_onehot && grads, "lipasr_mlp_train_fwd_bwd: null argument");
+  LP_CHECK_ARG(m->n_state == 0 || bnstate, "lipasr_mlp_train_fwd_bwd: bnstate is null");
+  LP_CHECK_ARG(!dropout || (dropout->mode >= 0 && dropout->mode <= 2), "lipasr_mlp_train_fwd_bwd: dropout mode %d",
+               dropout ? dropout->mode : 0);
+  hipStream_t st = S(stream);
+  const int Lc = m->n_layers;
+  const int C = m->L[Lc - 1].n_out;
+  float* ws = m->ws;
+
+  // ---- forward (training mode)
+  const float* hin = x;
+  for (int l = 0; l < Lc; ++l) {
+    const MlpLayer& L = m->L[l];
+    const bool last = (l == Lc - 1);
+    float* outp = last ? (ws + m->offLogits) : (ws + L.offA);
+    GemmArgs g = gemm_args(hin, L.n_in, params + L.offW, L.n_out, outp, L.n_out, batch, L.n_out, L.n_in,
+                           last ? EPI_BIAS : EPI_BIAS_RELU);
+    g.bias = params + L.offb;
+    rc = launch_gemm(0, 1, g, st);
+    if (rc != LIPASR_OK) return rc;
+    if (!last && L.offH != L.offA) {
+      BnFwdArgs b;
+      memset(&b, 0, sizeof(b));
+      b.a = ws + L.offA; b.h = ws + L.offH; b.B = batch; b.N = L.n_out; b.has_bn = L.bn ? 1 : 0;
+      if (L.bn) {
+        b.gamma = params + L.offg; b.beta = params + L.offbe;
+        b.mmean = bnstate + L.offmm; b.mvar = bnstate + L.offmv;
+        b.save_mean = ws + L.offMean;
+      }
+      b.drop = drop_for_layer(m, l, dropout);
+      hipLaunchKernelGGL(bn_fwd_train_kernel, dim3((L.n_out + 31) / 32), dim3(256), 0, st, b);
+      LP_LAUNCH_CHECK();
+      hin = ws + L.offH;
+    } else {
+      hin = outp;
+    }
+  }
+  // ---- loss and gradient at the logits
+  hipLaunchKernelGGL(softmax_ce_kernel, dim3((batch + 255) / 256), dim3(256), 0, st, ws + m->offLogits, y_onehot, batch, C,
+                     inv_batch, probs ? probs : (ws + m->offProb), ws + m->offDzLast, loss_rows, correct_rows,
+                     (float*)nullptr);
+  LP_LAUNCH_CHECK();
+
+  // ---- backward
+  const float* gin = ws + m->offDzLast;  // gradient at layer l's pre-activation
+  for (int l = Lc - 1; l >= 0; --l) {
+    const MlpLayer& L = m->L[l];
+    const bool last = (l == Lc - 1);
+    if (last) {
+      hipLaunchKernelGGL(colsum_kernel, dim3((L.n_out + 31) / 32), dim3(256), 0, st, gin, batch, L.n_out,
+                         grads + L.offb);
+      LP_LAUNCH_CHECK();
+    } else {
+      BnBwdArgs b;
+      memset(&b, 0, sizeof(b));
+      b.dh = ws + m->offG0; b.a = ws + L.offA; b.dz = ws + m->offG1; b.B = batch; b.N = L.n_out;
+      b.has_bn = L.bn ? 1 : 0;
+      if (L.bn) {
+        b.gamma = params + L.offg; b.save_mean = ws + L.offMean;
+        b.dgamma = grads + L.offg; b.dbeta = grads + L.offbe;
+      }
+      b.db = grads + L.offb;
+      b.drop = drop_for_layer(m, l, dropout);
+      hipLaunchKernelGGL(bn_bwd_kernel, dim3((L.n_out + 31) / 32), dim3(256), 0, st, b);
+      LP_LAUNCH_CHECK();
+      gin = ws + m->offG1;
+    }
+    const float* lin = (l == 0) ? x : (ws + m->L[l - 1].offH);
+    // dW[n_in][n_out] = lin^T[n_in][B] * gin[B][n_out]   (both operands K(=batch)-strided)
+    GemmArgs gw = gemm_args(lin, L.n_in, gin, L.n_out, grads + L.offW, L.n_out, L.n_in, L.n_out, batch, EPI_STORE);
+    rc = launch_gemm(1, 1, gw, st);
+    if (rc != LIPASR_OK) return rc;
+    if (l > 0) {
+      // dh_prev[B][n_in] = gin[B][n_out] * W^T
+      GemmArgs gx = gemm_args(gin, L.n_out, params + L.offW, L.n_out, ws + m->offG0, L.n_in, batch, L.n_in, L.n_out,
+                              EPI_STORE);
+      rc = launch_gemm(0, 0, gx, st);
+      if (rc != LIPASR_OK) return rc;
+    }
+  }
+  return LIPASR_OK;
+}
+
+int lipasr_mlp_predict(lipasr_mlp_t m, const float* params, const float* bnstate, const float* x, int batch,
+                       float* probs, float* logits, lipasr_stream_t stream) {
+  int rc = check_batch("lipasr_mlp_predict", m, batch);
+  if (rc != LIPASR_OK) return rc;
+  LP_CHECK_ARG(params && x && (probs || logits), "lipasr_mlp_predict: null argument");
+  LP_CHECK_ARG(m->n_state == 0 || bnstate, "lipasr_mlp_predict: bnstate is null");
+  float* lg = logits ? logits : (m->ws + m->offLogits);
+  rc = forward_infer(m, params, bnstate, x, batch, false, lg, S(stream));
+  if (rc != LIPASR_OK) return rc;
+  if (probs) {
+    const int C = m->L[m->n_layers - 1].n_out;
+    hipLaunchKernelGGL(softmax_ce_kernel, dim3((batch + 255) / 256), dim3(256), 0, S(stream), lg, (const float*)nullptr,
+                       batch, C, 0.0f, probs, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr);
+    LP_LAUNCH_CHECK();
+  }
+  return LIPASR_OK;
+}
+
+int lipasr_mlp_own_labels(lipasr_mlp_t m, const float* params, const float* bnstate, const float* x, int batch,
+                          float* y_onehot_out, lipasr_stream_t stream) {
+  int rc = check_batch("lipasr_mlp_own_labels", m, batch);
+  if (rc != LIPASR_OK) return rc;
+  LP_CHECK_ARG(params && x && y_onehot_out, "lipasr_mlp_own_labels: null argument");
+  LP_CHECK_ARG(m->n_state == 0 || bnstate, "lipasr_mlp_own_labels: bnstate is null");
+  float* lg = m->ws + m->offLogits;
+  rc = forward_infer(m, params, bnstate, x, batch, false, lg, S(stream));
+  if (rc != LIPASR_OK) return rc;
+  const int C = m->L[m->n_layers - 1].n_out;
+  hipLaunchKernelGGL(softmax_ce_kernel, dim3((batch + 255) / 256), dim3(256), 0, S(stream), lg, (const float*)nullptr,
+                     batch, C, 0.0f, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, y_onehot_out);
+  LP_LAUNCH_CHECK();
+  return LIPASR_OK;
+}
+
+static int attack_common(lipasr_mlp_t m, const float* params, const float* bnstate, const float* x_eval,
+                         const float* y_onehot, int batch, float* dx, float* x_adv, const float* x0, float alpha,
+                         float eps, hipStream_t st) {
+  float* lg = m->ws + m->offLogits;
+  int rc = forward_infer(m, params, bnstate, x_eval, batch, true, lg, st);
+  if (rc != LIPASR_OK) return rc;
+  const int C = m->L[m->n_layers - 1].n_out;
+  hipLaunchKernelGGL(softmax_ce_kernel, dim3((batch + 255) / 256), dim3(256), 0, st, lg, y_onehot, batch, C,
+                     1.0f / (float)batch, m->ws + m->offProb, m->ws + m->offDzLast, (float*)nullptr, (float*)nullptr,
+                     (float*)nullptr);
+  LP_LAUNCH_CHECK();
+  return backward_infer(m, params, bnstate, batch, dx, x_adv, x0, alpha, eps, st);
+}
+
+int lipasr_mlp_input_grad(lipasr_mlp_t m, const float* params, const float* bnstate, const float* x,
+                          const float* y_onehot, int batch, float* dx, lipasr_stream_t stream) {
+  int rc = check_batch("lipasr_mlp_input_grad", m, batch);
+  if (rc != LIPASR_OK) return rc;
+  LP_CHECK_ARG(params && x && y_onehot && dx, "lipasr_mlp_input_grad: null argument");
+  LP_CHECK_ARG(m->n_state == 0 || bnstate, "lipasr_mlp_input_grad: bnstate is null");
+  return attack_common(m, params, bnstate, x, y_onehot, batch, dx, nullptr, nullptr, 0.0f, 0.0f, S(stream));
+}
+
+int lipasr_mlp_attack_step(lipasr_mlp_t m, const float* params, const float* bnstate, float* x_adv, const float* x0,
+                           const float* y_onehot, int batch, float alpha, float eps, lipasr_stream_t stream) {
+  int rc = check_batch("lipasr_mlp_attack_step", m, batch);
+  if (rc != LIPASR_OK) return rc;
+  LP_CHECK_ARG(params && x_adv && x0 && y_onehot, "lipasr_mlp_attack_step: null argument");
+  LP_CHECK_ARG(m->n_state == 0 || bnstate, "lipasr_mlp_attack_step: bnstate is null");
+  LP_CHECK_ARG(eps >= 0.0f && !(alpha != alpha), "lipasr_mlp_attack_step: eps=%g alpha=%g", (double)eps, (double)alpha);
+  return attack_common(m, params, bnstate, x_adv, y_onehot, batch, nullptr, x_adv, x0, alpha, eps, S(stream));
+}
+
+}  // extern "C"

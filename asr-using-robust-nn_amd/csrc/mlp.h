@@ -1,0 +1,36 @@
+// The dense-classifier plan shared by dense.hip (forward/backward) and optim.hip (Adam, projections).
+#pragma once
+#include "common.h"
+
+namespace lipasr {
+
+struct MlpLayer {
+  int n_in = 0, n_out = 0;
+  bool bn = false, nonneg = false;
+  float dropout = 0.f;
+  // offsets in floats into the flat trainable buffer (params / grads / adam m, v)
+  size_t offW = 0, offb = 0, offg = 0, offbe = 0;
+  // offsets in floats into bnstate
+  size_t offmm = 0, offmv = 0;
+  // offsets in floats into the plan workspace
+  size_t offA = 0;     // post-ReLU activations [max_batch][n_out]            (hidden layers)
+  size_t offH = 0;     // post-BN/dropout activations = next layer's input     (== offA if neither)
+  size_t offMean = 0;  // saved batch mean [n_out], rstd follows at offMean + n_out (BN layers)
+};
+
+constexpr float kBnMomentum = 0.99f;  // Keras BatchNormalization defaults (train_constraints.py:68)
+constexpr float kBnEps = 1e-3f;
+
+}  // namespace lipasr
+
+struct lipasr_mlp {
+  lipasr_ctx* ctx = nullptr;
+  int n_layers = 0;
+  int max_batch = 0;
+  int max_width = 0;
+  lipasr::MlpLayer L[LIPASR_MAX_LAYERS];
+  size_t n_params = 0, n_state = 0;
+  float* ws = nullptr;  // workspace
+  size_t ws_floats = 0;
+  size_t offLogits = 0, offProb = 0, offDzLast = 0, offG0 = 0, offG1 = 0, offLossTmp = 0;
+};

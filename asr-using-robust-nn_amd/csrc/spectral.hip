@@ -1,0 +1,679 @@
+// K3: Lipschitz projections on the device (gfx950).
+//
+//   product variant  (simple_norm_constraint, Constraints.py:135-189; get_lipschitz_constrained,
+//                     extract_features_construct_dataset.py:169-196)
+//     cst = W_m^T ... W_1^T is R x n_0 with R = number of classes (<= 32).  It is formed by m-1
+//     skinny chain steps  P <- P * W_k^T  (each output element is a dot product along a contiguous
+//     row of W_k: one wavefront per row, 64-lane DPP/shuffle reduction, W read exactly once), the
+//     last step also emits per-workgroup partial Gram matrices P P^T in fp64.  One small kernel
+//     sums the partials in a fixed order, takes lambda_max by repeated squaring
+//     (lambda_max <= tr(G^(2^J))^(1/2^J) <= R^(1/2^J) lambda_max, J = 40), derives every scale factor
+//     of the sequential pass in closed form and writes them to scratch; a last multi-tensor kernel
+//     applies them.  No host round trip, bitwise reproducible (no float atomics), so data-parallel
+//     replicas stay identical.
+//
+//   per-layer variant (norm_constraint, Constraints.py:9-33; get_norms,
+//                      extract_features_construct_dataset.py:154-161)
+//     power iteration on W^T W, all layers batched in each launch, warm-started from the previous
+//     step's right singular vector.  u = W v: one wavefront per row; v = W^T u: 32 columns x 8 row
+//     lanes per workgroup with an LDS tree, fixed summation order.
+#include "common.h"
+
+namespace lipasr {
+
+constexpr double kEps = 2.220446049250313e-16;  // np.spacing(1), Constraints.py:25,167
+constexpr int kMaxR = 32;
+constexpr int kMaxOrder = 64;
+constexpr int kChainRowsPerWave = 2;
+constexpr int kChainRowsPerBlock = 4 * kChainRowsPerWave;
+constexpr int kSquarings = 40;
+
+// ---------------------------------------------------------------------------------------------
+// chain step: P_out[r][i] = sum_j P_in[r][j] * W[i][j],  i < n_rows, j < n_in, r < R
+//   p_mode 0: P_in is R x n_in row-major
+//   p_mode 1: P_in[r][j] = Wlast[j*R + r]   (P = W_m^T read straight from the last kernel)
+//   p_mode 2: P_in = identity (R == n_in)    (single-layer model: P_out = W^T)
+// emit_gram: also write this block's partial Gram  sum_i P_out[:,i] P_out[:,i]^T  (fp64, R*R)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void chain_step_kernel(const float* __restrict__ Pin, int p_mode,
+                                                          const float* __restrict__ W, int n_rows, int n_in, int R,
+                                                          float* __restrict__ Pout, int emit_gram,
+                                                          double* __restrict__ gram_part) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* Ps = reinterpret_cast<float*>(smem_raw);                      // [R][n_in]
+  float* rowsum = Ps + (size_t)R * n_in;                               // [4][32]
+  double* gsm = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(rowsum + 4 * kMaxR) + 7) & ~uintptr_t(7));  // [4][R*R]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int total = R * n_in;
+  if (p_mode == 0) {
+    for (int f = tid; f < total; f += 256) Ps[f] = Pin[f];
+  } else if (p_mode == 1) {
+    for (int f = tid; f < total; f += 256) {
+      int j = f / R, r = f - j * R;
+      Ps[r * n_in + j] = Pin[f];
+    }
+  } else {
+    for (int f = tid; f < total; f += 256) {
+      int r = f / n_in, j = f - r * n_in;
+      Ps[f] = (r == j) ? 1.0f : 0.0f;
+    }
+  }
+  const int RR = R * R;
+  double gacc[(kMaxR * kMaxR) / 64];
+#pragma unroll
+  for (int q = 0; q < (kMaxR * kMaxR) / 64; ++q) gacc[q] = 0.0;
+  __syncthreads();
+
+  const bool vec = ((n_in & 3) == 0) && ((reinterpret_cast<uintptr_t>(W) & 15) == 0);
+  for (int rr = 0; rr < kChainRowsPerWave; ++rr) {
+    const int i = blockIdx.x * kChainRowsPerBlock + wave * kChainRowsPerWave + rr;
+    const bool live = i < n_rows;  // wave-uniform
+    float acc[kMaxR];
+#pragma unroll
+    for (int r = 0; r < kMaxR; ++r) acc[r] = 0.0f;
+    if (live) {
+      const float* wrow = W + (size_t)i * n_in;
+      if (vec) {
+        for (int j = lane * 4; j < n_in; j += 256) {
+          const float4 w = *reinterpret_cast<const float4*>(wrow + j);
+#pragma unroll
+          for (int r = 0; r < kMaxR; ++r) {
+            if (r < R) {
+              const float4 p = *reinterpret_cast<const float4*>(Ps + r * n_in + j);
+              acc[r] = fmaf(w.x, p.x, acc[r]);
+              acc[r] = fmaf(w.y, p.y, acc[r]);
+              acc[r] = fmaf(w.z, p.z, acc[r]);
+              acc[r] = fmaf(w.w, p.w, acc[r]);
+            }
+          }
+        }
+      } else {
+        for (int j = lane; j < n_in; j += 64) {
+          const float w = wrow[j];
+#pragma unroll
+          for (int r = 0; r < kMaxR; ++r)
+            if (r < R) acc[r] = fmaf(w, Ps[r * n_in + j], acc[r]);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < kMaxR; ++r)
+      if (r < R) acc[r] = wave_sum(acc[r]);
+    if (live && lane == 0) {
+#pragma unroll
+      for (int r = 0; r < kMaxR; ++r)
+        if (r < R) Pout[(size_t)r * n_rows + i] = acc[r];
+    }
+    if (emit_gram) {
+      // publish this row's R sums to the wave's LDS slot, then each lane adds its Gram entries
+      if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < kMaxR; ++r)
+          if (r < R) rowsum[wave * kMaxR + r] = live ? acc[r] : 0.0f;
+      }
+      __builtin_amdgcn_wave_barrier();
+      __threadfence_block();
+#pragma unroll
+      for (int q = 0; q < (kMaxR * kMaxR) / 64; ++q) {
+        const int e = lane + 64 * q;
+        if (e < RR) {
+          const int a = e / R, b = e - a * R;
+          gacc[q] += (double)rowsum[wave * kMaxR + a] * (double)rowsum[wave * kMaxR + b];
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  if (emit_gram) {
+#pragma unroll
+    for (int q = 0; q < (kMaxR * kMaxR) / 64; ++q) {
+      const int e = lane + 64 * q;
+      if (e < RR) gsm[wave * RR + e] = gacc[q];
+    }
+    __syncthreads();
+    for (int e = tid; e < RR; e += 256)
+      gram_part[(size_t)blockIdx.x * RR + e] = (gsm[e] + gsm[RR + e]) + (gsm[2 * RR + e] + gsm[3 * RR + e]);
+  }
+}
+
+struct OrderArgs {
+  int n_layers;
+  int n_order;
+  int order[kMaxOrder];
+};
+
+// One workgroup: G = sum of partial Grams; sigma = sqrt(lambda_max(G)); closed-form sequential scales.
+__global__ __launch_bounds__(256) void product_sigma_kernel(const double* __restrict__ gram_part, int n_part, int R,
+                                                             double rho, OrderArgs oa, float* __restrict__ scales,
+                                                             float* __restrict__ norms_out, float* __restrict__ sigma_out) {
+  __shared__ double A[kMaxR * kMaxR];
+  __shared__ double B[kMaxR * kMaxR];
+  __shared__ double tr_s;
+  const int tid = threadIdx.x;
+  const int RR = R * R;
+  for (int e = tid; e < RR; e += 256) {
+    double s = 0.0;
+    for (int p = 0; p < n_part; ++p) s += gram_part[(size_t)p * RR + e];
+    A[e] = s;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double t = 0.0;
+    for (int a = 0; a < R; ++a) t += A[a * R + a];
+    tr_s = t;
+  }
+  __syncthreads();
+  const double t0 = tr_s;
+  double log_lambda = 0.0;
+  bool zero = !(t0 > 0.0);
+  if (!zero) {
+    log_lambda = log(t0);
+    for (int e = tid; e < RR; e += 256) A[e] /= t0;
+    __syncthreads();
+    double wgt = 0.5;
+    for (int it = 0; it < kSquarings; ++it) {
+      for (int e = tid; e < RR; e += 256) {
+        const int a = e / R, b = e - a * R;
+        double s = 0.0;
+        for (int c = 0; c < R; ++c) s = fma(A[a * R + c], A[c * R + b], s);
+        B[e] = s;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        double t = 0.0;
+        for (int a = 0; a < R; ++a) t += B[a * R + a];
+        tr_s = t;
+      }
+      __syncthreads();
+      const double tj = tr_s;
+      log_lambda += wgt * log(tj);
+      wgt *= 0.5;
+      for (int e = tid; e < RR; e += 256) A[e] = B[e] / tj;
+      __syncthreads();
+      if (fabs(tj - 1.0) < 1e-15) break;  // A is a rank-1 projector: converged (uniform across threads)
+    }
+  }
+  if (tid == 0) {
+    const double sigma = zero ? 0.0 : exp(0.5 * log_lambda);
+    if (sigma_out) *sigma_out = (float)sigma;
+    if (scales) {
+      double sc[LIPASR_MAX_LAYERS];
+      for (int l = 0; l < oa.n_layers; ++l) sc[l] = 1.0;
+      double n = sigma;
+      const double inv_m = 1.0 / (double)oa.n_layers;
+      for (int v = 0; v < oa.n_order; ++v) {
+        norms_out[v] = (float)n;
+        const double s = pow(rho / (n + kEps), inv_m);
+        sc[oa.order[v]] *= s;
+        n *= s;
+      }
+      norms_out[oa.n_order] = (float)n;
+      for (int l = 0; l < oa.n_layers; ++l) scales[l] = (float)sc[l];
+    }
+  }
+}
+
+struct LayerPtrs {
+  int n_layers;
+  float* W[LIPASR_MAX_LAYERS];
+  int rows[LIPASR_MAX_LAYERS];
+  int cols[LIPASR_MAX_LAYERS];
+};
+
+// blockIdx.y = layer; W_l *= scales[l] (skipped when the factor is exactly 1)
+__global__ __launch_bounds__(256) void scale_layers_kernel(LayerPtrs lp, const float* __restrict__ scales) {
+  const int l = blockIdx.y;
+  const float s = scales[l];
+  if (s == 1.0f) return;
+  float* w = lp.W[l];
+  const size_t n = (size_t)lp.rows[l] * lp.cols[l];
+  const size_t stride = (size_t)gridDim.x * 256;
+  if ((reinterpret_cast<uintptr_t>(w) & 15) == 0) {
+    const size_t n4 = n >> 2;
+    float4* w4 = reinterpret_cast<float4*>(w);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+      float4 x = w4[i];
+      x.x *= s; x.y *= s; x.z *= s; x.w *= s;
+      w4[i] = x;
+    }
+    for (size_t i = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) w[i] *= s;
+  } else {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) w[i] *= s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// power iteration, all layers per launch
+// ---------------------------------------------------------------------------------------------
+struct PiArgs {
+  int n_layers;
+  const float* W[LIPASR_MAX_LAYERS];
+  int rows[LIPASR_MAX_LAYERS];
+  int cols[LIPASR_MAX_LAYERS];
+  float* v[LIPASR_MAX_LAYERS];   // [cols]
+  float* u[LIPASR_MAX_LAYERS];   // [rows]
+  int blk_u[LIPASR_MAX_LAYERS + 1];  // block prefix for the u kernel (8 rows per block)
+  int blk_v[LIPASR_MAX_LAYERS + 1];  // block prefix for the v kernel (32 columns per block)
+  int clamp;
+};
+
+constexpr int kPiMaxDim = 8192;
+
+__device__ __forceinline__ int find_layer(const int* prefix, int n, int blk) {
+  int l = 0;
+  while (l + 1 < n && blk >= prefix[l + 1]) ++l;
+  return l;
+}
+
+__device__ __forceinline__ float start_vec(int j) {
+  // fixed, strictly positive start vector (Perron direction for the clamped kernels)
+  return 1.0f + 0.001f * (float)((((unsigned)j * 2654435761u) >> 24) & 255u);
+}
+
+__device__ __forceinline__ float block_sum_256(float x, float* red) {
+  x = wave_sum(x);
+  const int tid = threadIdx.x;
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = x;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// u = max(W,0)? * (v / ||v||)
+__global__ __launch_bounds__(256) void pi_u_kernel(PiArgs a, int cold) {
+  __shared__ __attribute__((aligned(16))) float vs[kPiMaxDim];
+  __shared__ float red[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l = find_layer(a.blk_u, a.n_layers, blockIdx.x);
+  const int rows = a.rows[l], cols = a.cols[l];
+  const float* W = a.W[l];
+  float ss = 0.0f;
+  for (int j = tid; j < cols; j += 256) {
+    const float x = cold ? start_vec(j) : a.v[l][j];
+    vs[j] = x;
+    ss = fmaf(x, x, ss);
+  }
+  const float nv2 = block_sum_256(ss, red);
+  const float inv = nv2 > 0.0f ? 1.0f / sqrtf(nv2) : 0.0f;
+  const bool vec = ((cols & 3) == 0) && ((reinterpret_cast<uintptr_t>(W) & 15) == 0);
+  const int row0 = (blockIdx.x - a.blk_u[l]) * 8 + wave * 2;
+  for (int rr = 0; rr < 2; ++rr) {
+    const int i = row0 + rr;
+    if (i >= rows) break;  // wave-uniform
+    const float* wrow = W + (size_t)i * cols;
+    float acc = 0.0f;
+    if (vec) {
+      for (int j = lane * 4; j < cols; j += 256) {
+        float4 w = *reinterpret_cast<const float4*>(wrow + j);
+        const float4 p = *reinterpret_cast<const float4*>(vs + j);
+        if (a.clamp) { w.x = fmaxf(w.x, 0.f); w.y = fmaxf(w.y, 0.f); w.z = fmaxf(w.z, 0.f); w.w = fmaxf(w.w, 0.f); }
+        acc = fmaf(w.x, p.x, acc); acc = fmaf(w.y, p.y, acc); acc = fmaf(w.z, p.z, acc); acc = fmaf(w.w, p.w, acc);
+      }
+    } else {
+      for (int j = lane; j < cols; j += 64) {
+        float w = wrow[j];
+        if (a.clamp) w = fmaxf(w, 0.f);
+        acc = fmaf(w, vs[j], acc);
+      }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) a.u[l][i] = acc * inv;
+  }
+}
+
+// v = max(W,0)?^T u   (unnormalised; the next pi_u normalises)
+__global__ __launch_bounds__(256) void pi_v_kernel(PiArgs a) {
+  __shared__ float us[kPiMaxDim];
+  __shared__ float part[8][33];
+  const int tid = threadIdx.x, cx = tid & 31, ry = tid >> 5;
+  const int l = find_layer(a.blk_v, a.n_layers, blockIdx.x);
+  const int rows = a.rows[l], cols = a.cols[l];
+  const float* W = a.W[l];
+  for (int i = tid; i < rows; i += 256) us[i] = a.u[l][i];
+  __syncthreads();
+  const int j = (blockIdx.x - a.blk_v[l]) * 32 + cx;
+  float acc = 0.0f;
+  if (j < cols) {
+#pragma unroll 4
+    for (int i = ry; i < rows; i += 8) {
+      float w = W[(size_t)i * cols + j];
+      if (a.clamp) w = fmaxf(w, 0.f);
+      acc = fmaf(w, us[i], acc);
+    }
+  }
+  part[ry][cx] = acc;
+  __syncthreads();
+  if (ry == 0 && j < cols) {
+    float s = ((part[0][cx] + part[1][cx]) + (part[2][cx] + part[3][cx])) +
+              ((part[4][cx] + part[5][cx]) + (part[6][cx] + part[7][cx]));
+    a.v[l][j] = s;
+  }
+}
+
+// sigma_l = ||u_l|| (u = W v_hat); optionally W_l <- max(W_l,0) * c / (sigma_l + eps).  blockIdx.y = layer.
+__global__ __launch_bounds__(256) void pi_finish_kernel(PiArgs a, double c, int do_scale, float* __restrict__ sigmas_out) {
+  __shared__ float red[4];
+  const int tid = threadIdx.x;
+  const int l = blockIdx.y;
+  const int rows = a.rows[l], cols = a.cols[l];
+  float ss = 0.0f;
+  for (int i = tid; i < rows; i += 256) {
+    const float x = a.u[l][i];
+    ss = fmaf(x, x, ss);
+  }
+  const float s2 = block_sum_256(ss, red);
+  const float sigma = sqrtf(s2);
+  if (blockIdx.x == 0 && tid == 0) sigmas_out[l] = sigma;
+  if (!do_scale) return;
+  const double f = c / ((double)sigma + kEps);
+  float* w = const_cast<float*>(a.W[l]);
+  const size_t n = (size_t)rows * cols;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + tid; i < n; i += stride) {
+    const float x = fmaxf(w[i], 0.0f);
+    w[i] = (float)((double)x * f);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Frobenius projection (customConstraint) and BN correction factor
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sumsq_clamped_kernel(const float* __restrict__ w, size_t n, double* __restrict__ part) {
+  __shared__ double red[4];
+  double s = 0.0;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const float x = fmaxf(w[i], 0.0f);
+    s += (double)x * (double)x;
+  }
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void frob_scale_kernel(float* __restrict__ w, size_t n, const double* __restrict__ part,
+                                                          int n_part, double rho) {
+  __shared__ double tot;
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int p = 0; p < n_part; ++p) s += part[p];
+    tot = s;
+  }
+  __syncthreads();
+  const float f = (float)(rho / (sqrt(tot) + kEps));
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) w[i] = fmaxf(w[i], 0.0f) * f;
+}
+
+__global__ __launch_bounds__(256) void bn_correction_kernel(const float* __restrict__ gamma, const float* __restrict__ var,
+                                                             int n, float* __restrict__ out) {
+  __shared__ float red[4];
+  float m = -INFINITY;
+  for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, sqrtf(var[i]) / gamma[i]);
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) *out = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static int check_layers(const char* fn, const float* const* Ws, const int* rows, const int* cols, int n_layers,
+                        bool need_chain) {
+  LP_CHECK_ARG(Ws && rows && cols, "%s: null layer arrays", fn);
+  LP_CHECK_ARG(n_layers >= 1 && n_layers <= LIPASR_MAX_LAYERS, "%s: n_layers=%d outside [1,%d]", fn, n_layers,
+               LIPASR_MAX_LAYERS);
+  for (int l = 0; l < n_layers; ++l) {
+    LP_CHECK_ARG(Ws[l] != nullptr, "%s: kernel %d is null", fn, l);
+    LP_CHECK_ARG(rows[l] >= 1 && cols[l] >= 1, "%s: kernel %d has shape %dx%d", fn, l, rows[l], cols[l]);
+    if (need_chain && l > 0)
+      LP_CHECK_ARG(rows[l] == cols[l - 1], "%s: kernel %d has %d inputs but kernel %d has %d outputs", fn, l, rows[l],
+                   l - 1, cols[l - 1]);
+  }
+  return LIPASR_OK;
+}
+
+// Scratch layout (floats): [0, 64)       scales / sigma
+//                          [64, ...)      two ping-pong P buffers, then the fp64 Gram partials
+struct ChainScratch {
+  float* scales;
+  float* sigma;
+  float* P[2];
+  double* gram;
+  size_t gram_cap_doubles;
+};
+
+static int carve_scratch(lipasr_ctx* h, int R, int max_width, ChainScratch* cs) {
+  const size_t pbuf = ((size_t)R * max_width + 63) & ~size_t(63);
+  const size_t need = 64 + 2 * pbuf;
+  if (need + 1024 > h->scratch_floats) {
+    set_error("product chain: %d classes x width %d exceeds the handle's scratch", R, max_width);
+    return LIPASR_EUNSUPPORTED;
+  }
+  cs->scales = h->scratch;
+  cs->sigma = h->scratch + 32;
+  cs->P[0] = h->scratch + 64;
+  cs->P[1] = h->scratch + 64 + pbuf;
+  cs->gram = reinterpret_cast<double*>(h->scratch + 64 + 2 * pbuf);
+  cs->gram_cap_doubles = (h->scratch_floats - (64 + 2 * pbuf)) / 2;
+  return LIPASR_OK;
+}
+
+// Launches the chain; on return the Gram partials are in cs.gram (n_part blocks).
+static int launch_chain(lipasr_ctx* h, const float* const* Ws, const int* rows, const int* cols, int m,
+                        ChainScratch* cs, int* n_part_out, hipStream_t st) {
+  const int R = cols[m - 1];
+  if (R > kMaxR) {
+    set_error("product chain: last layer has %d outputs; the Gram eigen-solver handles at most %d", R, kMaxR);
+    return LIPASR_EUNSUPPORTED;
+  }
+  int max_width = 0;
+  for (int l = 0; l < m; ++l) max_width = rows[l] > max_width ? rows[l] : max_width;
+  int rc = carve_scratch(h, R, max_width, cs);
+  if (rc != LIPASR_OK) return rc;
+
+  const float* pin = Ws[m - 1];
+  int p_mode = 1;
+  int cur = 0;
+  if (m == 1) {
+    // P = W_1^T: run one step against the identity so the Gram falls out of the same kernel
+    pin = nullptr;
+    p_mode = 2;
+  }
+  const int first_k = (m == 1) ? 0 : m - 2;
+  for (int k = first_k; k >= 0; --k) {
+    // step k multiplies by W_k^T: rows of W_k are the new columns of P
+    const int n_rows = rows[k];
+    const int n_in = (m == 1) ? R : cols[k];
+    const int emit = (k == 0) ? 1 : 0;
+    const int blocks = (n_rows + kChainRowsPerBlock - 1) / kChainRowsPerBlock;
+    const size_t lds = (size_t)R * n_in * sizeof(float) + 4 * kMaxR * sizeof(float) +
+                       (emit ? (size_t)4 * R * R * sizeof(double) : 0) + 16;
+    if (lds > 160 * 1024 - 512) {
+      set_error("product chain: %d x %d panel does not fit LDS", R, n_in);
+      return LIPASR_EUNSUPPORTED;
+    }
+    if (emit && (size_t)blocks * R * R > cs->gram_cap_doubles) {
+      set_error("product chain: Gram partials exceed scratch");
+      return LIPASR_EUNSUPPORTED;
+    }
+    if (lds > 48 * 1024)
+      LP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_step_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const float* Wk = (m == 1) ? Ws[0] : Ws[k];
+    hipLaunchKernelGGL(chain_step_kernel, dim3(blocks), dim3(256), lds, st, pin, p_mode, Wk, n_rows, n_in, R,
+                       cs->P[cur], emit, cs->gram);
+    LP_LAUNCH_CHECK();
+    if (emit) *n_part_out = blocks;
+    pin = cs->P[cur];
+    p_mode = 0;
+    cur ^= 1;
+  }
+  (void)h;
+  return LIPASR_OK;
+}
+
+static int fill_pi_args(PiArgs* a, const float* const* Ws, const int* rows, const int* cols, int n_layers,
+                        float* v_state, float* u_scratch, size_t u_cap, int clamp) {
+  a->n_layers = n_layers;
+  a->clamp = clamp;
+  size_t voff = 0, uoff = 0;
+  a->blk_u[0] = 0;
+  a->blk_v[0] = 0;
+  for (int l = 0; l < n_layers; ++l) {
+    if (rows[l] > kPiMaxDim || cols[l] > kPiMaxDim) {
+      set_error("power iteration: kernel %d is %dx%d; dimensions above %d are not supported", l, rows[l], cols[l],
+                kPiMaxDim);
+      return LIPASR_EUNSUPPORTED;
+    }
+    a->W[l] = Ws[l];
+    a->rows[l] = rows[l];
+    a->cols[l] = cols[l];
+    a->v[l] = v_state + voff;
+    a->u[l] = u_scratch + uoff;
+    voff += cols[l];
+    uoff += (rows[l] + 3) & ~3;
+    a->blk_u[l + 1] = a->blk_u[l] + (rows[l] + 7) / 8;
+    a->blk_v[l + 1] = a->blk_v[l] + (cols[l] + 31) / 32;
+  }
+  if (uoff > u_cap) {
+    set_error("power iteration: left vectors exceed scratch");
+    return LIPASR_EUNSUPPORTED;
+  }
+  return LIPASR_OK;
+}
+
+static int run_power_iteration(lipasr_ctx* h, PiArgs& a, int warm, int iters, hipStream_t st) {
+  (void)h;
+  const int nbu = a.blk_u[a.n_layers], nbv = a.blk_v[a.n_layers];
+  int cold = warm ? 0 : 1;
+  for (int it = 0; it < iters; ++it) {
+    hipLaunchKernelGGL(pi_u_kernel, dim3(nbu), dim3(256), 0, st, a, cold);
+    LP_LAUNCH_CHECK();
+    cold = 0;
+    hipLaunchKernelGGL(pi_v_kernel, dim3(nbv), dim3(256), 0, st, a);
+    LP_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(pi_u_kernel, dim3(nbu), dim3(256), 0, st, a, cold);
+  LP_LAUNCH_CHECK();
+  if (cold) {
+    // iters == 0 on a cold start: still leave a defined warm-start vector behind
+    hipLaunchKernelGGL(pi_v_kernel, dim3(nbv), dim3(256), 0, st, a);
+    LP_LAUNCH_CHECK();
+  }
+  return LIPASR_OK;
+}
+
+}  // namespace lipasr
+
+using namespace lipasr;
+
+extern "C" {
+
+int lipasr_sigma_max(lipasr_handle_t h, const float* W, int rows, int cols, float* v_state, int warm, int iters,
+                     int clamp_nonneg, float* sigma_out, lipasr_stream_t stream) {
+  LP_CHECK_ARG(h && W && v_state && sigma_out, "lipasr_sigma_max: null argument");
+  LP_CHECK_ARG(rows >= 1 && cols >= 1 && iters >= 0, "lipasr_sigma_max: bad shape %dx%d or iters %d", rows, cols, iters);
+  const float* Ws[1] = {W};
+  PiArgs a;
+  int rc = fill_pi_args(&a, Ws, &rows, &cols, 1, v_state, h->scratch + 64, h->scratch_floats - 64, clamp_nonneg);
+  if (rc != LIPASR_OK) return rc;
+  rc = run_power_iteration(h, a, warm, iters, S(stream));
+  if (rc != LIPASR_OK) return rc;
+  hipLaunchKernelGGL(pi_finish_kernel, dim3(1, 1), dim3(256), 0, S(stream), a, 0.0, 0, sigma_out);
+  LP_LAUNCH_CHECK();
+  return LIPASR_OK;
+}
+
+int lipasr_project_per_layer(lipasr_handle_t h, float* const* Ws, const int* rows, const int* cols, int n_layers,
+                             float rho, float* v_state, int warm, int iters, float* sigmas_out,
+                             lipasr_stream_t stream) {
+  LP_CHECK_ARG(h && v_state && sigmas_out, "lipasr_project_per_layer: null argument");
+  int rc = check_layers("lipasr_project_per_layer", Ws, rows, cols, n_layers, false);
+  if (rc != LIPASR_OK) return rc;
+  LP_CHECK_ARG(iters >= 0, "lipasr_project_per_layer: iters=%d", iters);
+  LP_CHECK_ARG(rho > 0.0f, "lipasr_project_per_layer: rho=%g must be positive", (double)rho);
+  PiArgs a;
+  rc = fill_pi_args(&a, Ws, rows, cols, n_layers, v_state, h->scratch + 64, h->scratch_floats - 64, 1);
+  if (rc != LIPASR_OK) return rc;
+  rc = run_power_iteration(h, a, warm, iters, S(stream));
+  if (rc != LIPASR_OK) return rc;
+  const double c = pow((double)rho, 1.0 / (double)n_layers);  // np.power(rho, 1/self.m), Constraints.py:25
+  hipLaunchKernelGGL(pi_finish_kernel, dim3(64, n_layers), dim3(256), 0, S(stream), a, c, 1, sigmas_out);
+  LP_LAUNCH_CHECK();
+  return LIPASR_OK;
+}
+
+int lipasr_project_product(lipasr_handle_t h, float* const* Ws, const int* rows, const int* cols, int n_layers,
+                           float rho, const int* order, int n_order, float* norms_out, lipasr_stream_t stream) {
+  LP_CHECK_ARG(h && norms_out, "lipasr_project_product: null argument");
+  int rc = check_layers("lipasr_project_product", Ws, rows, cols, n_layers, true);
+  if (rc != LIPASR_OK) return rc;
+  LP_CHECK_ARG(n_order >= 0 && n_order <= kMaxOrder, "lipasr_project_product: n_order=%d outside [0,%d]", n_order,
+               kMaxOrder);
+  LP_CHECK_ARG(n_order == 0 || order != nullptr, "lipasr_project_product: order is null");
+  LP_CHECK_ARG(rho > 0.0f, "lipasr_project_product: rho=%g must be positive", (double)rho);
+  OrderArgs oa;
+  oa.n_layers = n_layers;
+  oa.n_order = n_order;
+  for (int v = 0; v < n_order; ++v) {
+    LP_CHECK_ARG(order[v] >= 0 && order[v] < n_layers, "lipasr_project_product: order[%d]=%d out of range", v, order[v]);
+    oa.order[v] = order[v];
+  }
+  ChainScratch cs;
+  int n_part = 0;
+  rc = launch_chain(h, Ws, rows, cols, n_layers, &cs, &n_part, S(stream));
+  if (rc != LIPASR_OK) return rc;
+  hipLaunchKernelGGL(product_sigma_kernel, dim3(1), dim3(256), 0, S(stream), cs.gram, n_part, cols[n_layers - 1],
+                     (double)rho, oa, cs.scales, norms_out, cs.sigma);
+  LP_LAUNCH_CHECK();
+  if (n_order > 0) {
+    LayerPtrs lp;
+    lp.n_layers = n_layers;
+    for (int l = 0; l < n_layers; ++l) { lp.W[l] = Ws[l]; lp.rows[l] = rows[l]; lp.cols[l] = cols[l]; }
+    hipLaunchKernelGGL(scale_layers_kernel, dim3(64, n_layers), dim3(256), 0, S(stream), lp, cs.scales);
+    LP_LAUNCH_CHECK();
+  }
+  return LIPASR_OK;
+}
+
+int lipasr_product_norm(lipasr_handle_t h, const float* const* Ws, const int* rows, const int* cols, int n_layers,
+                        float* sigma_out, lipasr_stream_t stream) {
+  LP_CHECK_ARG(h && sigma_out, "lipasr_product_norm: null argument");
+  int rc = check_layers("lipasr_product_norm", Ws, rows, cols, n_layers, true);
+  if (rc != LIPASR_OK) return rc;
+  ChainScratch cs;
+  int n_part = 0;
+  rc = launch_chain(h, Ws, rows, cols, n_layers, &cs, &n_part, S(stream));
+  if (rc != LIPASR_OK) return rc;
+  OrderArgs oa;
+  oa.n_layers = n_layers;
+  oa.n_order = 0;
+  hipLaunchKernelGGL(product_sigma_kernel, dim3(1), dim3(256), 0, S(stream), cs.gram, n_part, cols[n_layers - 1], 1.0,
+                     oa, (float*)nullptr, (float*)nullptr, sigma_out);
+  LP_LAUNCH_CHECK();
+  return LIPASR_OK;
+}
+
+int lipasr_frobenius_project(lipasr_handle_t h, float* W, size_t n, float rho, lipasr_stream_t stream) {
+  LP_CHECK_ARG(h && W && n > 0, "lipasr_frobenius_project: null or empty kernel");
+  double* part = reinterpret_cast<double*>(h->scratch + 64);
+  const int nb = 256;
+  hipLaunchKernelGGL(sumsq_clamped_kernel, dim3(nb), dim3(256), 0, S(stream), W, n, part);
+  LP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(frob_scale_kernel, dim3(nb), dim3(256), 0, S(stream), W, n, part, nb, (double)rho);
+  LP_LAUNCH_CHECK();
+  return LIPASR_OK;
+}
+
+int lipasr_bn_correction(lipasr_handle_t h, const float* gamma, const float* var, int n, float* out,
+                         lipasr_stream_t stream) {
+  LP_CHECK_ARG(h && gamma && var && out && n > 0, "lipasr_bn_correction: bad argument");
+  hipLaunchKernelGGL(bn_correction_kernel, dim3(1), dim3(256), 0, S(stream), gamma, var, n, out);
+  LP_LAUNCH_CHECK();
+  return LIPASR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,179 @@
+"""ctypes binding of liblipasr.so (include/lipasr.h).
+
+The product has no CPU fallback: if the shared library is missing, importing this module raises.
+Device memory, streams and process groups come from PyTorch (plumbing); every arithmetic step on
+the hot path goes through the C ABI below.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblipasr.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not found: build it with `python asr-using-robust-nn_amd/build.py` "
+        "(or __graft_entry__.build()).  lipasr has no CPU fallback."
+    )
+
+lib = C.CDLL(LIB_PATH)
+
+OK, EINVAL, ENOMEM, EHIP, EUNSUPPORTED, ESTATE = 0, -1, -2, -3, -4, -5
+MAX_LAYERS = 16
+SEG_W, SEG_B, SEG_GAMMA, SEG_BETA, SEG_MMEAN, SEG_MVAR = range(6)
+
+c_f = C.c_void_p  # device float*
+c_h = C.c_void_p
+c_s = C.c_void_p
+i32 = C.c_int
+f32 = C.c_float
+u64 = C.c_uint64
+sz = C.c_size_t
+PI = C.POINTER(C.c_int)
+PV = C.POINTER(C.c_void_p)
+
+
+class DropoutCfg(C.Structure):
+    _fields_ = [("mode", C.c_int), ("seed", C.c_uint64), ("step_dev", C.c_void_p), ("masks", PV)]
+
+
+# name -> (restype, argtypes); mirrors include/lipasr.h line by line
+PROTOTYPES = {
+    "lipasr_version": (i32, []),
+    "lipasr_last_error": (C.c_char_p, []),
+    "lipasr_create": (i32, [i32, C.POINTER(c_h)]),
+    "lipasr_destroy": (i32, [c_h]),
+    "lipasr_timer_create": (i32, [c_h, PI]),
+    "lipasr_timer_start": (i32, [c_h, i32, c_s]),
+    "lipasr_timer_stop": (i32, [c_h, i32, c_s]),
+    "lipasr_timer_elapsed_ms": (i32, [c_h, i32, C.POINTER(f32)]),
+    "lipasr_graph_begin": (i32, [c_h, c_s]),
+    "lipasr_graph_end": (i32, [c_h, c_s, PI]),
+    "lipasr_graph_launch": (i32, [c_h, i32, c_s]),
+    "lipasr_graph_destroy": (i32, [c_h, i32]),
+    "lipasr_sigma_max": (i32, [c_h, c_f, i32, i32, c_f, i32, i32, i32, c_f, c_s]),
+    "lipasr_project_per_layer": (i32, [c_h, PV, PI, PI, i32, f32, c_f, i32, i32, c_f, c_s]),
+    "lipasr_project_product": (i32, [c_h, PV, PI, PI, i32, f32, PI, i32, c_f, c_s]),
+    "lipasr_product_norm": (i32, [c_h, PV, PI, PI, i32, c_f, c_s]),
+    "lipasr_frobenius_project": (i32, [c_h, c_f, sz, f32, c_s]),
+    "lipasr_bn_correction": (i32, [c_h, c_f, c_f, i32, c_f, c_s]),
+    "lipasr_sign_step": (i32, [c_h, c_f, c_f, c_f, sz, f32, f32, c_s]),
+    "lipasr_scaler_fit": (i32, [c_h, c_f, i32, i32, c_f, c_f, c_s]),
+    "lipasr_scaler_apply": (i32, [c_h, c_f, i32, i32, c_f, c_f, c_f, c_s]),
+    "lipasr_gemm_f32": (i32, [c_h, i32, i32, i32, i32, i32, c_f, i32, c_f, i32, c_f, i32, c_s]),
+    "lipasr_mlp_create": (i32, [c_h, i32, PI, PI, C.POINTER(f32), PI, i32, C.POINTER(c_h)]),
+    "lipasr_mlp_destroy": (i32, [c_h]),
+    "lipasr_mlp_sizes": (i32, [c_h, C.POINTER(sz), C.POINTER(sz)]),
+    "lipasr_mlp_segment": (i32, [c_h, i32, i32, C.POINTER(sz), C.POINTER(sz)]),
+    "lipasr_mlp_train_fwd_bwd": (i32, [c_h, c_f, c_f, c_f, c_f, i32, f32, C.POINTER(DropoutCfg), c_f, c_f, c_f, c_f, c_s]),
+    "lipasr_mlp_adam_nonneg": (i32, [c_h, c_f, c_f, c_f, c_f, c_f, f32, f32, f32, f32, f32, c_s]),
+    "lipasr_mlp_project_product": (i32, [c_h, c_f, f32, PI, i32, c_f, c_s]),
+    "lipasr_mlp_project_per_layer": (i32, [c_h, c_f, f32, c_f, i32, i32, c_f, c_s]),
+    "lipasr_mlp_product_norm": (i32, [c_h, c_f, c_f, c_s]),
+    "lipasr_mlp_predict": (i32, [c_h, c_f, c_f, c_f, i32, c_f, c_f, c_s]),
+    "lipasr_mlp_input_grad": (i32, [c_h, c_f, c_f, c_f, c_f, i32, c_f, c_s]),
+    "lipasr_mlp_attack_step": (i32, [c_h, c_f, c_f, c_f, c_f, c_f, i32, f32, f32, c_s]),
+    "lipasr_mlp_own_labels": (i32, [c_h, c_f, c_f, c_f, i32, c_f, c_s]),
+    "lipasr_mfcc_plan": (i32, [c_h, i32, i32, i32]),
+    "lipasr_mfcc_dims": (i32, [c_h, PI, PI]),
+    "lipasr_mfcc_f32": (i32, [c_h, c_f, i32, i32, c_f, c_f, c_f, c_s]),
+    "lipasr_resample_f32": (i32, [c_h, c_f, i32, c_f, c_s]),
+    "lipasr_mfcc_from_22k": (i32, [c_h, c_f, i32, i32, i32, c_f, c_f, c_f, c_s]),
+    "lipasr_mfcc_profile_begin": (i32, [c_h, i32]),
+    "lipasr_mfcc_profile_end": (i32, [c_h, C.POINTER(f32), PI]),
+    "lipasr_add_noise_f32": (i32, [c_h, c_f, i32, i32, i32, f32, f32, u64, c_s]),
+    "lipasr_debug_table": (i32, [i32, i32, C.POINTER(f32), i32]),
+}
+
+for _name, (_res, _args) in PROTOTYPES.items():
+    _fn = getattr(lib, _name)  # AttributeError here = header and library out of sync
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def last_error() -> str:
+    return (lib.lipasr_last_error() or b"").decode("utf-8", "replace")
+
+
+class LipasrError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"liblipasr error {code}: {msg}")
+        self.code = code
+
+
+def check(rc: int) -> int:
+    """Raise for a negative return code: ValueError for LIPASR_EINVAL, LipasrError otherwise."""
+    if rc >= 0:
+        return rc
+    msg = last_error()
+    if rc == EINVAL:
+        raise ValueError(f"liblipasr: {msg}")
+    raise LipasrError(rc, msg)
+
+
+def int_array(values):
+    arr = (C.c_int * max(1, len(values)))(*[int(v) for v in values])
+    return arr
+
+
+def float_array(values):
+    return (C.c_float * max(1, len(values)))(*[float(v) for v in values])
+
+
+def ptr_array(ptrs):
+    return (C.c_void_p * max(1, len(ptrs)))(*[C.c_void_p(int(p) if p else None) for p in ptrs])
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_handles = {}
+
+
+class Handle:
+    """One lipasr handle per (process, device)."""
+
+    def __init__(self, device: int):
+        self.device = device
+        h = c_h()
+        check(lib.lipasr_create(device, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            lib.lipasr_destroy(self.h)
+            self.h = None
+
+
+def get_handle(device=None) -> Handle:
+    import torch
+
+    if not torch.cuda.is_available():
+        raise RuntimeError("lipasr needs an MI355X (gfx950) GPU: torch.cuda.is_available() is False and there is no CPU path")
+    if device is None:
+        device = torch.cuda.current_device()
+    if device not in _handles:
+        _handles[device] = Handle(device)
+    return _handles[device]
+
+
+def debug_table(which: int, sr_in: int = 16000):
+    """Host-only constant tables as the kernels read them (numpy float32)."""
+    import numpy as np
+
+    n = check(lib.lipasr_debug_table(which, sr_in, None, 0))
+    out = np.zeros(n, dtype=np.float32)
+    check(lib.lipasr_debug_table(which, sr_in, out.ctypes.data_as(C.POINTER(C.c_float)), n))
+    return out

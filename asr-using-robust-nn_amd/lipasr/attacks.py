@@ -1,0 +1,256 @@
+"""attacks.py surface of the reference (attacks.py:48-86, 145-294, 496-536, 647-693) over liblipasr.
+
+White-box: ``TensorFlowV2Classifier`` / ``FastGradientMethod`` / ``ProjectedGradientDescent`` keep
+the ART constructor keywords the reference uses (``estimator=``, ``eps=``) plus the ART defaults it
+relies on (norm=inf, eps_step=0.1, max_iter=100, batch_size=32, untargeted, y=None -> the model's own
+predictions, no clip_values).  Each PGD iteration is ONE native call: inference forward, CE gradient,
+backward to the input and the sign step fused into the last backward GEMM's epilogue (K4).
+
+Black-box: ``standardize_dataset`` (A2, fp64-accumulated fit on the device), the audio-domain noise
+models on the device (Philox RNG) and the noisy-audio -> MFCC dataset helpers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _native as N
+from .extract_features_construct_dataset import MfccExtractor, read_wav, _extractor
+from .keras import Model
+
+
+def _dev():
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _to_dev(x):
+    t = x if torch.is_tensor(x) else torch.as_tensor(np.asarray(x))
+    return t.to(device=_dev(), dtype=torch.float32).contiguous()
+
+
+# ------------------------------------------------------------------------------------------------ A2
+class StandardScaler:
+    """sklearn.preprocessing.StandardScaler restricted to fit / transform / fit_transform, on the device.
+    Statistics are fp64 (mean_, scale_ are float64 device tensors, as sklearn's are float64 arrays)."""
+
+    def fit(self, x):
+        xt = _to_dev(x)
+        h = N.get_handle(xt.device.index)
+        self.mean_ = torch.zeros(xt.shape[1], dtype=torch.float64, device=xt.device)
+        self.scale_ = torch.zeros(xt.shape[1], dtype=torch.float64, device=xt.device)
+        N.check(N.lib.lipasr_scaler_fit(h.h, N.ptr(xt), xt.shape[0], xt.shape[1], N.ptr(self.mean_), N.ptr(self.scale_), N.stream_ptr()))
+        return self
+
+    def transform_device(self, xt):
+        h = N.get_handle(xt.device.index)
+        out = torch.empty_like(xt)
+        N.check(N.lib.lipasr_scaler_apply(h.h, N.ptr(xt), xt.shape[0], xt.shape[1], N.ptr(self.mean_), N.ptr(self.scale_), N.ptr(out), N.stream_ptr()))
+        return out
+
+    def transform(self, x):
+        out = self.transform_device(_to_dev(x))
+        return out if torch.is_tensor(x) else out.cpu().numpy()
+
+    def fit_transform(self, x):
+        return self.fit(x).transform(x)
+
+
+def standardize_dataset(train_data, val_data, test_data):
+    """attacks.py:48-69 / train_constraints.py:28-35: fit on the concatenation, split back."""
+    parts = [_to_dev(train_data), _to_dev(val_data), _to_dev(test_data)]
+    all_data = torch.cat(parts, dim=0)
+    out = StandardScaler().fit(all_data).transform_device(all_data)
+    a, b = parts[0].shape[0], parts[0].shape[0] + parts[1].shape[0]
+    res = (out[:a], out[a:b], out[b:])
+    if torch.is_tensor(train_data):
+        return res
+    return tuple(r.cpu().numpy() for r in res)
+
+
+# ------------------------------------------------------------------------------------------------ A9 / A10
+class TensorFlowV2Classifier:
+    """ART estimator wrapper (attacks.py:500-504): ``predict`` and ``loss_gradient`` over a lipasr Model."""
+
+    def __init__(self, model, nb_classes, input_shape, loss_object=None, clip_values=None):
+        if not isinstance(model, Model):
+            raise TypeError("model must be a lipasr.keras.Model")
+        if clip_values is not None:
+            raise NotImplementedError("the reference passes no clip_values")
+        self.model, self.nb_classes, self.input_shape = model, int(nb_classes), tuple(input_shape)
+        if model._n_classes != self.nb_classes or model._widths[0] != self.input_shape[0]:
+            raise ValueError("nb_classes / input_shape do not match the model")
+
+    def predict(self, x, batch_size=128):
+        return self.model.predict(x)
+
+    def loss_gradient(self, x, y):
+        """d mean CE(f(x), y) / dx in inference mode, NumPy in / NumPy out."""
+        m = self.model
+        xt, yt = _to_dev(x), _to_dev(y)
+        out = torch.empty_like(xt)
+        bs = m._max_batch
+        for s in range(0, xt.shape[0], bs):
+            xb, yb, ob = xt[s:s + bs], yt[s:s + bs], out[s:s + bs]
+            N.check(N.lib.lipasr_mlp_input_grad(m._plan, N.ptr(m._params), N.ptr(m._bnstate), N.ptr(xb), N.ptr(yb), xb.shape[0], N.ptr(ob), N.stream_ptr()))
+        return out.cpu().numpy()
+
+
+class _SignAttack:
+    def __init__(self, estimator, eps, eps_step, max_iter, batch_size, norm, targeted, num_random_init):
+        if not isinstance(estimator, TensorFlowV2Classifier):
+            raise TypeError("estimator must be a lipasr TensorFlowV2Classifier")
+        if norm not in (np.inf, "inf", math.inf):
+            raise NotImplementedError("only norm=inf (the ART default the reference uses) is implemented")
+        if targeted or num_random_init:
+            raise NotImplementedError("targeted / random-init variants are not used by the reference")
+        self.estimator, self.eps, self.eps_step = estimator, float(eps), float(eps_step)
+        self.max_iter, self.batch_size = int(max_iter), int(batch_size)
+
+    def _labels(self, m, xb, y):
+        if y is not None:
+            return y
+        yb = torch.empty(xb.shape[0], m._n_classes, device=xb.device)
+        N.check(N.lib.lipasr_mlp_own_labels(m._plan, N.ptr(m._params), N.ptr(m._bnstate), N.ptr(xb), xb.shape[0], N.ptr(yb), N.stream_ptr()))
+        return yb
+
+    def generate_device(self, xt, yt=None):
+        """x: float32 device tensor; returns a NEW device tensor (the input is left untouched)."""
+        m = self.estimator.model
+        adv = xt.clone()
+        bs = min(self.batch_size, m._max_batch)
+        for s in range(0, xt.shape[0], bs):
+            x0 = xt[s:s + bs]
+            xa = adv[s:s + bs]
+            yb = self._labels(m, x0, None if yt is None else yt[s:s + bs])
+            self._run(m, xa, x0, yb)
+        return adv
+
+    def generate(self, x, y=None):
+        xt = _to_dev(x)
+        yt = None if y is None else _to_dev(y)
+        adv = self.generate_device(xt, yt)
+        return adv if torch.is_tensor(x) else adv.cpu().numpy().astype(np.asarray(x).dtype, copy=False)
+
+
+class FastGradientMethod(_SignAttack):
+    """ART FastGradientMethod(estimator=, eps=) (attacks.py:506-510): x + eps * sign(grad), one step, no clipping."""
+
+    def __init__(self, estimator, eps=0.3, batch_size=32, norm=np.inf, targeted=False, num_random_init=0):
+        super().__init__(estimator, eps, eps, 1, batch_size, norm, targeted, num_random_init)
+
+    def _run(self, m, xa, x0, yb):
+        N.check(N.lib.lipasr_mlp_attack_step(m._plan, N.ptr(m._params), N.ptr(m._bnstate), N.ptr(xa), N.ptr(x0), N.ptr(yb), xa.shape[0],
+                                             self.eps, math.inf, N.stream_ptr()))
+
+
+class ProjectedGradientDescent(_SignAttack):
+    """ART ProjectedGradientDescent(estimator=, eps=) (attacks.py:657-661): max_iter steps of
+    x <- x0 + clip(x + eps_step * sign(grad) - x0, -eps, eps)."""
+
+    def __init__(self, estimator, eps=0.3, eps_step=0.1, max_iter=100, batch_size=32, norm=np.inf, targeted=False, num_random_init=0):
+        super().__init__(estimator, eps, eps_step, max_iter, batch_size, norm, targeted, num_random_init)
+
+    def _run(self, m, xa, x0, yb):
+        for _ in range(self.max_iter):
+            N.check(N.lib.lipasr_mlp_attack_step(m._plan, N.ptr(m._params), N.ptr(m._bnstate), N.ptr(xa), N.ptr(x0), N.ptr(yb), xa.shape[0],
+                                                 self.eps_step, self.eps, N.stream_ptr()))
+
+
+def sign_step(x_adv, x0, g, alpha, eps):
+    """Stand-alone K4 on device tensors, in place on x_adv."""
+    h = N.get_handle(x_adv.device.index)
+    N.check(N.lib.lipasr_sign_step(h.h, N.ptr(x_adv), N.ptr(x0), N.ptr(g), x_adv.numel(), float(alpha), float(eps), N.stream_ptr()))
+    return x_adv
+
+
+# ------------------------------------------------------------------------------------------------ A12 (device noise)
+_noise_calls = [0]
+
+
+def _noise(arr, mode, p0, p1, seed):
+    was_tensor = torch.is_tensor(arr)
+    t = _to_dev(arr).clone()
+    one_d = t.dim() == 1
+    if one_d:
+        t = t[None, :]
+    if seed is None:
+        _noise_calls[0] += 1
+        seed = 0xA77AC000 + _noise_calls[0]
+    h = N.get_handle(t.device.index)
+    N.check(N.lib.lipasr_add_noise_f32(h.h, N.ptr(t), t.shape[0], t.shape[1], mode, float(p0), float(p1), int(seed), N.stream_ptr()))
+    if one_d:
+        t = t[0]
+    return t if was_tensor else t.cpu().numpy()
+
+
+def add_white_noise(array, sigma, seed=None):
+    """attacks.py:73-86: array + N(0, sigma)."""
+    return _noise(array, 0, sigma, 0.0, seed)
+
+
+def add_noise(x, p, alpha, seed=None):
+    """attacks.py:166-183 (mixtgauss :145-163): impulse mixture, sigma0 = alpha, sigma1 = 10 alpha, peaks where |N(0,1)| < p."""
+    return _noise(x, 1, p, alpha, seed)
+
+
+def add_white_noise_with_snr(audio, target_snr_db, seed=None):
+    """attacks.py:222-245: white noise whose power sits target_snr_db below the clip's mean power."""
+    return _noise(audio, 2, target_snr_db, 0.0, seed)
+
+
+def add_white_noise_on_dataset(dataset, sigma, seed=None):
+    """attacks.py:186-201: white noise on every row of an MFCC matrix."""
+    return _noise(dataset, 0, sigma, 0.0, seed)
+
+
+def add_noise_mixture_on_dataset(dataset, p, alpha, seed=None):
+    """attacks.py:204-219."""
+    return _noise(dataset, 1, p, alpha, seed)
+
+
+def noisy_audio_to_mfcc(waves, sr_in=16000, sigma=0, p=0, alpha=0, target_snr_db=None, seed=None, utterance_length=44):
+    """The one end-to-end audio flow of the reference (attacks.py:89-121, 248-274) for a batch of clips:
+    resample -> add noise at 22 050 Hz -> MFCC -> (B, 20*utterance_length) device tensor."""
+    w = _to_dev(waves)
+    ex = _extractor(int(sr_in), w.shape[1], w.shape[0])
+    y = ex.resample(w)
+    if target_snr_db is not None:
+        y = add_white_noise_with_snr(y, target_snr_db, seed)
+    elif sigma != 0:
+        y = add_white_noise(y, sigma, seed)
+    elif p != 0 and alpha != 0:
+        y = add_noise(y, p, alpha, seed)
+    return ex.from_22k(y, utterance_length)
+
+
+def _files_to_batches(filenames):
+    groups = {}
+    for i, fn in enumerate(filenames):
+        x, sr = read_wav(fn)
+        groups.setdefault((sr, len(x)), []).append((i, x))
+    return groups
+
+
+def black_box_attack_on_audio_dataset(filenames, sigma, p, alpha, seed=None):
+    """attacks.py:124-142: noisy MFCC for a list of wav files, (N, 880) float64."""
+    out = np.zeros((len(filenames), 20 * 44))
+    for (sr, n), items in _files_to_batches(filenames).items():
+        w = np.stack([x for _, x in items])
+        f = noisy_audio_to_mfcc(w, sr, sigma=sigma, p=p, alpha=alpha, seed=seed).cpu().numpy()
+        for (i, _), row in zip(items, f):
+            out[i] = row
+    return out
+
+
+def black_box_attack_on_audio_dataset_snr(filenames, target_snr_db, seed=None):
+    """attacks.py:277-294."""
+    out = np.zeros((len(filenames), 20 * 44))
+    for (sr, n), items in _files_to_batches(filenames).items():
+        w = np.stack([x for _, x in items])
+        f = noisy_audio_to_mfcc(w, sr, target_snr_db=target_snr_db, seed=seed).cpu().numpy()
+        for (i, _), row in zip(items, f):
+            out[i] = row
+    return out

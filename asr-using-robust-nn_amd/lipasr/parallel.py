@@ -1,0 +1,95 @@
+"""Data parallelism for the training path: one process per GPU, the batch sharded
+into contiguous per-rank slices, ONE sum all-reduce per step over the flat fp32 gradient buffer
+(torch.distributed backend "nccl" = RCCL over xGMI on ROCm; "gloo" on CPU for tests), the 1/global
+batch factor folded into the loss gradient, then Adam + NonNeg + the Lipschitz projection run
+redundantly and deterministically on every replica (no second exchange; the kernels use no float
+atomics, so replicas stay bit-identical).  BatchNorm statistics are per replica.
+
+The reference has no counterpart (single process, train_constraints.py:91-105).
+
+A *replica* is anything with ``grads`` (flat tensor), ``train_fwd_bwd(x, y, inv_batch=..., **kw)`` and
+``apply_adam()`` -- ``lipasr.keras.Model`` on the GPU, a CPU stand-in in the gloo tests.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Join the process group described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun)."""
+    if dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1:
+        return 0, 1
+    rank = int(os.environ["RANK"])
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", rank)))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world
+
+
+def shard_bounds(n, rank, world):
+    """Contiguous shard [lo, hi) of n items for `rank`; the first n % world ranks get one extra item."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class DataParallel:
+    def __init__(self, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+
+    def shard(self, *tensors):
+        """This rank's contiguous slice of each global-batch tensor."""
+        out = []
+        for t in tensors:
+            lo, hi = shard_bounds(t.shape[0], self.rank, self.world)
+            out.append(t[lo:hi])
+        return out if len(out) > 1 else out[0]
+
+    def broadcast(self, *tensors, src=0):
+        if self.world > 1:
+            for t in tensors:
+                dist.broadcast(t, src=src, group=self.group)
+
+    def allreduce_grads(self, flat):
+        """The one collective of a step: in-place SUM over the flat gradient buffer."""
+        if self.world > 1:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        return flat
+
+    def train_step(self, replica, xb, yb, global_batch=None, **kw):
+        """xb, yb: this rank's shard.  Per-replica gradients carry 1/global_batch, so their SUM is the
+        gradient of the mean loss over the global batch."""
+        if global_batch is None:
+            global_batch = self.global_count(xb.shape[0])
+        replica.train_fwd_bwd(xb, yb, inv_batch=1.0 / float(global_batch), **kw)
+        self.allreduce_grads(replica.grads)
+        replica.apply_adam()
+
+    def global_count(self, local_n):
+        if self.world == 1:
+            return local_n
+        dev = "cuda" if dist.get_backend(self.group) == "nccl" else "cpu"
+        t = torch.tensor([local_n], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, group=self.group)
+        return int(t.item())
+
+    def max_divergence(self, flat):
+        """max |flat - rank0's flat| over ranks (0.0 when the replicas are in sync)."""
+        if self.world == 1:
+            return 0.0
+        ref = flat.clone()
+        dist.broadcast(ref, src=0, group=self.group)
+        d = (flat - ref).abs().max().reshape(1)
+        dist.all_reduce(d, op=dist.ReduceOp.MAX, group=self.group)
+        return float(d.item())

@@ -1,0 +1,274 @@
+/*
+ * lipasr.h -- C ABI of liblipasr.so: the MI355X (gfx950) hot path of
+ * fmazilu/ASR-using-robust-NN behind plain pointers and sizes.
+ *
+ * The reference has no FFI: its hot path sits behind Python duck-typed protocols
+ * (Keras Callback / Constraint, ART estimator / attack, librosa calls).  Every
+ * entry point below cites the reference interface (file:line, relative to
+ * "/root/reference/Voice digit recogniton/") whose arithmetic it replaces.
+ * INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *   - every function returns int: 0 = LIPASR_OK, negative = LIPASR_E*; nothing
+ *     throws across the ABI; lipasr_last_error() returns a thread-local message.
+ *   - all array pointers are DEVICE pointers owned by the caller unless the
+ *     parameter is documented "host".  The library allocates only per-handle /
+ *     per-plan workspaces (tables, scratch) at create/plan time, never inside a
+ *     launch function, so every launch function may be captured in a HIP graph.
+ *   - `stream` is a hipStream_t passed as void*; all work is stream-ordered; no
+ *     launch function synchronises the device.
+ *   - a handle / plan is re-entrant across handles, NOT thread-safe per handle:
+ *     one handle per GPU per process (one process per GPU under data parallel).
+ *   - Dense kernels use the Keras layout W(in, out), y = x @ W, row-major.
+ */
+#ifndef LIPASR_H
+#define LIPASR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LIPASR_OK            0
+#define LIPASR_EINVAL       -1   /* bad argument (null pointer, size, unsupported shape) */
+#define LIPASR_ENOMEM       -2   /* device allocation failed */
+#define LIPASR_EHIP         -3   /* a HIP runtime call failed (message has hipGetErrorString) */
+#define LIPASR_EUNSUPPORTED -4   /* valid request outside what the kernels implement */
+#define LIPASR_ESTATE       -5   /* call order violated (e.g. mfcc before mfcc_plan) */
+
+#define LIPASR_MAX_LAYERS   16
+#define LIPASR_N_MFCC       20   /* librosa.feature.mfcc default n_mfcc */
+#define LIPASR_N_MELS       128
+#define LIPASR_N_FFT        2048
+#define LIPASR_HOP          512
+#define LIPASR_SR           22050 /* librosa.load default sr */
+
+typedef struct lipasr_ctx* lipasr_handle_t;
+typedef struct lipasr_mlp* lipasr_mlp_t;
+typedef void* lipasr_stream_t; /* hipStream_t */
+
+/* ------------------------------------------------------------------ core */
+int lipasr_version(void);
+const char* lipasr_last_error(void);
+/* device: HIP device ordinal.  Allocates the handle's scratch workspace. */
+int lipasr_create(int device, lipasr_handle_t* out);
+int lipasr_destroy(lipasr_handle_t h);
+
+/* HIP-event timer on an explicit stream (bench.py times the stream the kernels run on). */
+int lipasr_timer_create(lipasr_handle_t h, int* timer_id);
+int lipasr_timer_start(lipasr_handle_t h, int timer_id, lipasr_stream_t stream);
+int lipasr_timer_stop(lipasr_handle_t h, int timer_id, lipasr_stream_t stream);
+/* synchronises on the stop event; host float out */
+int lipasr_timer_elapsed_ms(lipasr_handle_t h, int timer_id, float* ms_host);
+
+/* HIP-graph capture of any sequence of launch functions issued on `stream`. */
+int lipasr_graph_begin(lipasr_handle_t h, lipasr_stream_t stream);
+int lipasr_graph_end(lipasr_handle_t h, lipasr_stream_t stream, int* graph_id);
+int lipasr_graph_launch(lipasr_handle_t h, int graph_id, lipasr_stream_t stream);
+int lipasr_graph_destroy(lipasr_handle_t h, int graph_id);
+
+/* ------------------------------------------------------------------ K3: Lipschitz projections
+ * Ws: HOST array of n_layers DEVICE pointers to Dense kernels W_l (rows[l] x cols[l], row-major,
+ * rows = in, cols = out).  Scalars come back in DEVICE memory (no host sync). */
+
+/* sigma_max(W) by power iteration on W^T W  -- replaces np.linalg.norm(w, ord=2) at
+ * Constraints.py:24, extract_features_construct_dataset.py:158, train_constraints.py:58.
+ * v_state: device [cols] warm-start vector (in/out); warm=0 starts from a fixed positive vector.
+ * iters: number of (W v, W^T u) round trips before the final W v.  clamp_nonneg!=0 evaluates
+ * max(W,0) (the matrix norm_constraint projects, Constraints.py:23). */
+int lipasr_sigma_max(lipasr_handle_t h, const float* W, int rows, int cols, float* v_state, int warm,
+                     int iters, int clamp_nonneg, float* sigma_out, lipasr_stream_t stream);
+
+/* norm_constraint.on_batch_end (Constraints.py:27-33) with get_projection (:22-25) for every
+ * layer: W <- max(W,0) * rho^(1/m) / (sigma_max(max(W,0)) + 2.22e-16), m = n_layers (:15-20).
+ * v_state: device [sum(cols)] (layer l's vector at offset sum(cols[0..l-1])).
+ * sigmas_out: device [n_layers], the pre-scaling sigma_max of each clamped kernel. */
+int lipasr_project_per_layer(lipasr_handle_t h, float* const* Ws, const int* rows, const int* cols,
+                             int n_layers, float rho, float* v_state, int warm, int iters,
+                             float* sigmas_out, lipasr_stream_t stream);
+
+/* simple_norm_constraint.on_batch_end (Constraints.py:171-189) with get_projection (:158-169):
+ * visits order[0..n_order-1] (HOST array of layer indices, duplicates allowed; the caller builds
+ * it from affected_layers_indices exactly as :173-189 iterates), each visited kernel
+ * W <- W * (rho / (||W_m^T...W_1^T||_2 + 2.22e-16))^(1/m) with the product norm re-evaluated
+ * after every visit.  The product norm is computed ONCE on the device (chain of skinny GEMMs +
+ * Gram eigenvalue) and advanced in closed form, which is what the sequential re-evaluation
+ * amounts to.  norms_out: device [n_order+1]: product norm before each visit
+ * and after the last.  Requires cols[n_layers-1] <= 32 (the class dimension). */
+int lipasr_project_product(lipasr_handle_t h, float* const* Ws, const int* rows, const int* cols,
+                           int n_layers, float rho, const int* order, int n_order,
+                           float* norms_out, lipasr_stream_t stream);
+
+/* ||W_m^T ... W_1^T||_2 -- get_lipschitz_constrained's numerator
+ * (extract_features_construct_dataset.py:188-194). sigma_out: device [1]. */
+int lipasr_product_norm(lipasr_handle_t h, const float* const* Ws, const int* rows, const int* cols,
+                        int n_layers, float* sigma_out, lipasr_stream_t stream);
+
+/* customConstraint.__call__ (Constraints.py:43-46): W <- max(W,0) * rho / (||max(W,0)||_F + eps).
+ * tf.norm(w, ord=2) with axis=None is the Frobenius norm. */
+int lipasr_frobenius_project(lipasr_handle_t h, float* W, size_t n, float rho, lipasr_stream_t stream);
+
+/* max_j sqrt(var_j)/gamma_j -- one BatchNorm's correction factor
+ * (extract_features_construct_dataset.py:181-184). out: device [1]. */
+int lipasr_bn_correction(lipasr_handle_t h, const float* gamma, const float* var, int n, float* out,
+                         lipasr_stream_t stream);
+
+/* ------------------------------------------------------------------ K4: sign step
+ * ART FastGradientMethod / ProjectedGradientDescent update (attacks.py:506-510, 657-661),
+ * norm=inf, no clip_values: x_adv <- x0 + clip(x_adv + alpha*sign(g) - x0, -eps, +eps), in place.
+ * NaN gradients count as 0.  eps = +inf gives the plain FGSM step. */
+int lipasr_sign_step(lipasr_handle_t h, float* x_adv, const float* x0, const float* g, size_t n,
+                     float alpha, float eps, lipasr_stream_t stream);
+
+/* ------------------------------------------------------------------ A2: StandardScaler
+ * sklearn StandardScaler().fit_transform (train_constraints.py:28-31, attacks.py:61-63):
+ * per-feature mean and population std over N rows (accumulated in fp64), scale 1 for constant
+ * features.  mean_out/scale_out: device double [F]. */
+int lipasr_scaler_fit(lipasr_handle_t h, const float* x, int n_rows, int n_feat, double* mean_out,
+                      double* scale_out, lipasr_stream_t stream);
+int lipasr_scaler_apply(lipasr_handle_t h, const float* x, int n_rows, int n_feat, const double* mean,
+                        const double* scale, float* out, lipasr_stream_t stream);
+
+/* ------------------------------------------------------------------ K2: fp32 MFMA GEMM (exact fp32 fma chains)
+ * C[M,N] = op(A)[M,K] * op(B)[K,N]; transA=0: A is [M][lda]; transA=1: A is [K][lda] (A^T stored);
+ * transB=0: B is [K][ldb]; transB=1: B is [N][ldb]. */
+int lipasr_gemm_f32(lipasr_handle_t h, int transA, int transB, int M, int N, int K, const float* A,
+                    int lda, const float* B, int ldb, float* C, int ldc, lipasr_stream_t stream);
+
+/* ------------------------------------------------------------------ K2/K5: the dense classifier plan
+ * get_model() of train_constraints.py:63-88 / train_google_dataset.py:49-74 as data:
+ * n_layers Dense layers, widths[0..n_layers]; hidden layers are Dense(relu) [-> BatchNorm]
+ * [-> Dropout(rate)], the last is Dense(softmax).  bn/dropout entries for the last layer are
+ * ignored.  nonneg[l] != 0 puts Keras NonNeg on kernel l.
+ *
+ * Flat buffers (caller-owned, fp32):
+ *   params / grads / adam_m / adam_v : n_params floats, per layer [W | b | gamma | beta], every
+ *       segment start aligned to 4 floats (pad floats are zero and stay zero).  `grads` is the
+ *       data-parallel all-reduce buffer.
+ *   bnstate : n_state floats, per BN layer [moving_mean | moving_var].
+ */
+#define LIPASR_SEG_W      0
+#define LIPASR_SEG_B      1
+#define LIPASR_SEG_GAMMA  2
+#define LIPASR_SEG_BETA   3
+#define LIPASR_SEG_MMEAN  4  /* in bnstate */
+#define LIPASR_SEG_MVAR   5  /* in bnstate */
+
+int lipasr_mlp_create(lipasr_handle_t h, int n_layers, const int* widths, const int* bn,
+                      const float* dropout, const int* nonneg, int max_batch, lipasr_mlp_t* out);
+int lipasr_mlp_destroy(lipasr_mlp_t m);
+int lipasr_mlp_sizes(lipasr_mlp_t m, size_t* n_params, size_t* n_state);
+/* offset (in floats) and element count of one segment; count 0 if the layer has no such segment */
+int lipasr_mlp_segment(lipasr_mlp_t m, int layer, int kind, size_t* offset, size_t* count);
+
+/* dropout_mode: 0 = off, 1 = Philox mask from (seed, *step_dev, layer, element), 2 = masks given:
+ * dropout_masks is a HOST array of n_layers DEVICE pointers (or NULL entries) to [batch][width]
+ * multipliers (0 or 1/(1-rate)). */
+typedef struct lipasr_dropout_cfg {
+  int mode;
+  uint64_t seed;
+  const int* step_dev;              /* device int, may be NULL (counts as 0) */
+  const float* const* masks;        /* host array of device pointers, mode 2 */
+} lipasr_dropout_cfg;
+
+/* One training-mode forward + loss + backward: Keras train_step up to the optimizer
+ * (train_constraints.py:94-105 with get_model :63-88): Dense/ReLU, BatchNorm with batch statistics
+ * (momentum .99, eps 1e-3; moving stats updated in bnstate), inverted dropout, softmax +
+ * categorical cross-entropy from logits, gradient (p - y) * inv_batch at the logits.
+ * inv_batch = 1/global batch (data parallel: the all-reduce SUMS per-replica grads).
+ * Outputs: grads (flat, overwritten), loss_rows [batch] (-sum y log p per row), correct_rows
+ * [batch] (1.0 where argmax p == argmax y), probs [batch][classes] (may be NULL). */
+int lipasr_mlp_train_fwd_bwd(lipasr_mlp_t m, const float* params, float* bnstate, const float* x,
+                             const float* y_onehot, int batch, float inv_batch,
+                             const lipasr_dropout_cfg* dropout, float* grads, float* loss_rows,
+                             float* correct_rows, float* probs, lipasr_stream_t stream);
+
+/* K5: Keras Adam (optimizer='adam', train_constraints.py:94) then NonNeg (:67-85) in one launch
+ * over the flat buffers: g' = g*grad_scale; m = b1 m + (1-b1) g'; v = b2 v + (1-b2) g'^2;
+ * w -= lr*sqrt(1-b2^t)/(1-b1^t) * m / (sqrt(v) + eps); then w = w*[w>=0] on NonNeg kernels.
+ * step_dev: device int holding the number of updates already applied; t = *step_dev + 1 and the
+ * counter is incremented in-stream after the update. */
+int lipasr_mlp_adam_nonneg(lipasr_mlp_t m, float* params, const float* grads, float* adam_m,
+                           float* adam_v, int* step_dev, float lr, float beta1, float beta2, float eps,
+                           float grad_scale, lipasr_stream_t stream);
+
+/* Projections over the plan's kernels inside `params` (same semantics as the generic entry points). */
+int lipasr_mlp_project_product(lipasr_mlp_t m, float* params, float rho, const int* order, int n_order,
+                               float* norms_out, lipasr_stream_t stream);
+int lipasr_mlp_project_per_layer(lipasr_mlp_t m, float* params, float rho, float* v_state, int warm,
+                                 int iters, float* sigmas_out, lipasr_stream_t stream);
+int lipasr_mlp_product_norm(lipasr_mlp_t m, const float* params, float* sigma_out, lipasr_stream_t stream);
+
+/* model.predict (train_constraints.py:109, attacks.py:344): inference mode (BN moving statistics,
+ * no dropout).  probs and/or logits [batch][classes], either may be NULL. */
+int lipasr_mlp_predict(lipasr_mlp_t m, const float* params, const float* bnstate, const float* x,
+                       int batch, float* probs, float* logits, lipasr_stream_t stream);
+
+/* ART TensorFlowV2Classifier.loss_gradient in inference mode: dx = d mean_b CE(f(x_b), y_b) / dx. */
+int lipasr_mlp_input_grad(lipasr_mlp_t m, const float* params, const float* bnstate, const float* x,
+                          const float* y_onehot, int batch, float* dx, lipasr_stream_t stream);
+
+/* One fused FGSM/PGD iteration (attacks.py:506-510, 657-661): inference forward at x_adv, CE
+ * gradient, backward to the input, and the K4 sign step applied in place on x_adv inside the last
+ * backward GEMM's epilogue (dx never reaches memory). */
+int lipasr_mlp_attack_step(lipasr_mlp_t m, const float* params, const float* bnstate, float* x_adv,
+                           const float* x0, const float* y_onehot, int batch, float alpha, float eps,
+                           lipasr_stream_t stream);
+
+/* ART y=None: labels := one-hot argmax of the estimator's own prediction. */
+int lipasr_mlp_own_labels(lipasr_mlp_t m, const float* params, const float* bnstate, const float* x,
+                          int batch, float* y_onehot_out, lipasr_stream_t stream);
+
+/* ------------------------------------------------------------------ K1: MFCC
+ * extract_features / compute_mfcc_all_files (extract_features_construct_dataset.py:24-39,144-150):
+ * librosa.load(mono=True) resampling sr_in -> 22050 Hz (resampy kaiser_best), then
+ * librosa.feature.mfcc defaults (reflect-padded STFT 2048/512 periodic Hann, power, 128 Slaney
+ * mels, 10 log10 with amin 1e-10 and top_db 80 per clip, DCT-II ortho, 20 coefficients), frame
+ * axis truncated / zero-padded to utterance_length, flattened coefficient-major
+ * (index = coeff*utterance_length + frame).
+ *
+ * lipasr_mfcc_plan builds the tables for (sr_in, n_samp) and allocates intermediates for
+ * batch_max clips; it must precede the launch functions (not capturable itself). */
+int lipasr_mfcc_plan(lipasr_handle_t h, int sr_in, int n_samp, int batch_max);
+/* resampled length int(ceil(n_samp*22050/sr_in)) and frame count 1 + n_y/512 for a plan */
+int lipasr_mfcc_dims(lipasr_handle_t h, int* n_y, int* n_frames);
+
+/* wav: [batch][n_samp] float32 mono in [-1,1).  out: [batch][20*utterance_length].
+ * affine_mean / affine_scale: optional device double [20*utterance_length]; when given the output
+ * is (mfcc - mean)/scale (the precomputed StandardScaler of A2 fused into the last kernel). */
+int lipasr_mfcc_f32(lipasr_handle_t h, const float* wav, int batch, int utterance_length,
+                    const double* affine_mean, const double* affine_scale, float* out,
+                    lipasr_stream_t stream);
+/* stage 1 only: y [batch][n_y] (librosa.load output) */
+int lipasr_resample_f32(lipasr_handle_t h, const float* wav, int batch, float* y, lipasr_stream_t stream);
+/* stages 2..: from an already-resampled 22050 Hz signal y [batch][n_y] (the audio-noise attacks add
+ * noise here, attacks.py:108-114, 264-267). */
+int lipasr_mfcc_from_22k(lipasr_handle_t h, const float* y, int batch, int n_y, int utterance_length,
+                         const double* affine_mean, const double* affine_scale, float* out,
+                         lipasr_stream_t stream);
+
+/* Per-kernel HIP-event timing of the next `max_calls` lipasr_mfcc_f32 calls, recorded on the stream the
+ * kernels run on.  _end synchronises and returns the average milliseconds of {resample, stft_mel, dct}
+ * (host float[3]) and the number of calls measured (host int). */
+int lipasr_mfcc_profile_begin(lipasr_handle_t h, int max_calls);
+int lipasr_mfcc_profile_end(lipasr_handle_t h, float* avg_ms3, int* n_calls);
+
+/* A12 audio-domain noise on device, Philox RNG (attacks.py:73-86, 145-183, 222-245), in place on
+ * y [batch][n]:  mode 0: y + N(0, p0)               (add_white_noise, sigma = p0)
+ *                mode 1: impulse mixture, p = p0, alpha = p1 (add_noise / mixtgauss)
+ *                mode 2: white noise at target SNR p0 dB per clip (add_white_noise_with_snr) */
+int lipasr_add_noise_f32(lipasr_handle_t h, float* y, int batch, int n, int mode, float p0, float p1,
+                         uint64_t seed, lipasr_stream_t stream);
+
+/* Host-only (no GPU needed): copies one constant table, exactly as the kernels read it, into `out`
+ * and returns its element count (negative = error); out may be NULL to query the size.
+ * which: 0 Hann[2048]; 1 DCT[20*128]; 2 dense mel filter bank[128*1025]; 3 polyphase resampling taps
+ * [up*taps] for sr_in -> 22050; 4 {up, down, taps, left}; 5 per-phase input offsets [up]. */
+int lipasr_debug_table(int which, int sr_in, float* out, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIPASR_H */

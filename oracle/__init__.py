@@ -7,7 +7,7 @@ named in BASELINE.json (MFCC -> Lipschitz-constrained MLP -> FGSM/PGD).  Only
 product package (``asr-using-robust-nn_amd``) never imports it and has no CPU
 fallback: it raises if ``liblipasr.so`` is missing.
 
-Pinning status (see DESIGN.md "Oracle"): PARITY UNPINNED for every module.
+Pinning status (DESIGN.md section "Oracle"): PARITY UNPINNED for every module.
 
 The reference has no tests, golden vectors or stored outputs for this path, and none of its
 modules can be run here: each imports TensorFlow and/or librosa at top level, which are absent
@@ -22,6 +22,8 @@ NOT done: a stand-in for a library the image lacks is not a reference run.  So:
 * ``mlp_ref``    -- TensorFlow/Keras restated; checked by finite-difference gradients.
 * ``attacks_ref``-- ART restated.
 
-``tests/golden/*.npz`` are produced by THIS oracle (tests/golden/make_golden.py), not by the
-reference; they are regression vectors that also travel to the GPU box.
+The known-answer checks live in tests/test_oracle_cpu.py.  ``tests/golden/*.npz`` are produced by
+THIS oracle (tests/golden/make_golden.py), not by the reference; they are regression vectors that
+also travel to the GPU box.  The only reference-held data are the label arrays
+(``tests/golden/ref_labels.npz``: split sizes and class histograms).
 """

@@ -73,9 +73,11 @@ def simple_norm_constraint_pass(w_list, rho, affected_layers_indices=()):
     w_list = [np.asarray(w, dtype=np.float32).copy() for w in w_list]
     norms = []
     if len(affected_layers_indices) == 0:
-        order = range(len(w_list))
+        order = list(range(len(w_list)))
     else:
-        order = [i for i in reversed(range(len(w_list))) if i in set(affected_layers_indices)]
+        # :181-189: for index in reversed(range(m)): for layer_index in affected: if layer_index == index -> project
+        # (a layer listed twice is projected twice)
+        order = [index for index in reversed(range(len(w_list))) for layer_index in affected_layers_indices if layer_index == index]
     for i in order:
         norms.append(sigma_max(product_chain(w_list)))
         w_list[i] = simple_norm_projection(w_list[i], w_list, rho)
@@ -116,25 +118,35 @@ def fista_constraint(w, Y0, A, B, nit, rho):
     return w_new
 
 
-def fista_projection(w_index, w_list, rho, nit):
-    """get_projection (VD/Constraints.py:96-122) for the kernel at position ``w_index``.
+def fista_projection(w, w_list, rho, nit):
+    """get_projection (VD/Constraints.py:96-122) for the kernel ``w`` (Keras layout (in, out)).
 
+    The layer is located by VALUE equality, lowest matching index wins (:100-102).
     A = product of the LATER layers' transposes (identity for the last layer, :116-117),
     B = product of the EARLIER layers' transposes (identity for the first layer, :114-115).
-    Returns the new kernel in Keras layout (in, out) (the caller transposes back, :130)."""
-    w = np.asarray(w_list[w_index], dtype=np.float64)
+    dtypes follow the reference: kernels (and hence A, B, w.T) are float32 as get_weights() returns
+    them, the identities and Y0 are float64 (np.eye / np.zeros defaults), so the iteration promotes to
+    float64 from the first ``A.T @ Z @ B.T`` on.  Returns the new kernel in Keras layout (in, out)
+    (the caller transposes back, :130)."""
+    w = np.asarray(w)
+    w_index = None
+    for index in reversed(range(len(w_list))):
+        if np.array_equal(w, w_list[index]):
+            w_index = index
+    if w_index is None:
+        raise ValueError("kernel not found in w_list")
     A = None
     Bm = None
     for index in reversed(range(len(w_list))):
-        wt = np.asarray(w_list[index], dtype=np.float64).T
+        wt = np.array(w_list[index]).transpose()
         if index > w_index:
-            A = wt if A is None else A @ wt
+            A = wt if A is None else np.matmul(A, wt)
         elif index < w_index:
-            Bm = wt if Bm is None else Bm @ wt
+            Bm = wt if Bm is None else np.matmul(Bm, wt)
     if w_index == 0:
-        Bm = np.eye(w.shape[0])
+        Bm = np.eye(w.shape[0], w.shape[0])
     if w_index == len(w_list) - 1:
-        A = np.eye(w.shape[1])
+        A = np.eye(w.shape[1], w.shape[1])
     Y0 = np.zeros([A.shape[0], Bm.shape[1]])
     w_new = fista_constraint(w.T, Y0, A, Bm, nit, rho)
     return w_new.T.astype(np.float32)
@@ -144,7 +156,7 @@ def fista_pass(w_list, rho, nit):
     """on_batch_end (VD/Constraints.py:124-130): every dense layer in order, each seeing earlier updates."""
     w_list = [np.asarray(w, dtype=np.float32).copy() for w in w_list]
     for i in range(len(w_list)):
-        w_list[i] = fista_projection(i, w_list, rho, nit)
+        w_list[i] = fista_projection(w_list[i], w_list, rho, nit)
     return w_list
 
 

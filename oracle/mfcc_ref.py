@@ -166,6 +166,52 @@ def resample_kaiser_best_loop(x, sr_orig, sr_new):
     return y.astype(np.float32)
 
 
+@functools.lru_cache(maxsize=None)
+def _polyphase_table(sr_orig: int, sr_new: int):
+    """Per-output-phase taps of the kaiser_best interpolator for an up-sampling ratio L/M (float64).
+
+    Output t = L q + p always sees the fractional position (p M mod L)/L, so resampy's interpolated
+    weights can be tabulated once per phase: h[p] applies to x[M q + floor(p M / L) - 63 .. + 64]."""
+    g = int(np.gcd(sr_orig, sr_new))
+    L, Mdown = sr_new // g, sr_orig // g
+    assert sr_new > sr_orig, "table form is used for up-sampling only (exact step of 512)"
+    win, num_table = kaiser_best_half_window()
+    delta = np.zeros_like(win); delta[:-1] = np.diff(win)
+    wing = win.shape[0] // num_table  # 64
+    h = np.zeros((L, 2 * wing))
+    n_off = np.zeros(L, dtype=np.int64)
+    taps = np.arange(wing)
+    for p in range(L):
+        num = p * Mdown
+        n_off[p] = num // L
+        frac = (num % L) / L
+        idx_f = frac * num_table; off = int(idx_f); eta = idx_f - off
+        i_max = (win.shape[0] - off) // num_table
+        wl = np.where(taps < i_max, win[np.minimum(off + taps * num_table, win.shape[0] - 1)] + eta * delta[np.minimum(off + taps * num_table, win.shape[0] - 1)], 0.0)
+        h[p, wing - 1 - taps] = wl
+        idx_f = (1.0 - frac) * num_table; off = int(idx_f); eta = idx_f - off
+        k_max = (win.shape[0] - off) // num_table
+        wr = np.where(taps < k_max, win[np.minimum(off + taps * num_table, win.shape[0] - 1)] + eta * delta[np.minimum(off + taps * num_table, win.shape[0] - 1)], 0.0)
+        h[p, wing + taps] = wr
+    return h, n_off, L, Mdown, wing
+
+
+def resample_kaiser_best_fast(x: np.ndarray, sr_orig: int, sr_new: int) -> np.ndarray:
+    """Same result as resample_kaiser_best (to ~1e-7) for up-sampling, organised per phase so that it
+    runs at the speed of the reference's compiled resampler (used by bench.py's cpu_baseline leg)."""
+    x = np.asarray(x, dtype=np.float64)
+    h, n_off, L, Mdown, wing = _polyphase_table(sr_orig, sr_new)
+    n_out = int(x.shape[0] * (float(sr_new) / float(sr_orig)))
+    nq = (n_out + L - 1) // L
+    xp = np.concatenate([np.zeros(wing - 1), x, np.zeros(2 * wing + Mdown * (nq + 1) - 0)])
+    win = np.lib.stride_tricks.sliding_window_view(xp, 2 * wing)  # win[i] = x[i-63 .. i+64]
+    y = np.empty((nq, L))
+    base = Mdown * np.arange(nq)
+    for p in range(L):
+        y[:, p] = win[base + n_off[p]] @ h[p]
+    return y.reshape(-1)[:n_out].astype(np.float32)
+
+
 def hann_periodic(n: int = N_FFT) -> np.ndarray:
     """scipy.signal.get_window('hann', n, fftbins=True), float64."""
     return 0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(n) / n)
@@ -224,33 +270,42 @@ def reflect_pad(y: np.ndarray, pad: int) -> np.ndarray:
     return np.pad(y, pad, mode="reflect")
 
 
-def power_spectrogram(y: np.ndarray) -> np.ndarray:
-    """|STFT|^2 with librosa defaults (center=True, reflect, periodic Hann).  float32 [1025, T]."""
-    y = np.asarray(y, dtype=np.float32)
+def power_spectrogram(y: np.ndarray, dtype=np.float32) -> np.ndarray:
+    """|STFT|^2 with librosa defaults (center=True, reflect, periodic Hann).  [1025, T].
+
+    ``dtype=np.float32`` is the clean path (librosa.load returns float32, the STFT is stored complex64).
+    ``dtype=np.float64`` is what librosa <= 0.9 does for the noisy-audio paths of VD/attacks.py, where
+    ``raw_w + np.random.normal(...)`` is float64 and the STFT is inferred complex128."""
+    y = np.asarray(y, dtype=dtype)
+    ctype = np.complex64 if dtype == np.float32 else np.complex128
     yp = reflect_pad(y, N_FFT // 2)
     n_frames = 1 + (len(yp) - N_FFT) // HOP
     idx = np.arange(N_FFT)[:, None] + HOP * np.arange(n_frames)[None, :]
-    frames = yp[idx]  # [2048, T] float32
+    frames = yp[idx]  # [2048, T]
     win = hann_periodic(N_FFT)[:, None]  # float64
-    spec = np.fft.rfft(win * frames, axis=0).astype(np.complex64)
-    return (np.abs(spec) ** 2.0).astype(np.float32)
+    spec = np.fft.rfft(win * frames, axis=0).astype(ctype)
+    return (np.abs(spec) ** 2.0).astype(dtype)
 
 
 def power_to_db(S: np.ndarray, amin: float = 1e-10, top_db: float = 80.0) -> np.ndarray:
-    """librosa.power_to_db(S, ref=1.0, amin=1e-10, top_db=80)."""
-    S = np.asarray(S, dtype=np.float32)
-    log_spec = (10.0 * np.log10(np.maximum(np.float32(amin), S))).astype(np.float32)
+    """librosa.power_to_db(S, ref=1.0, amin=1e-10, top_db=80); keeps S's float dtype."""
+    S = np.asarray(S)
+    dt = S.dtype.type
+    log_spec = (10.0 * np.log10(np.maximum(dt(amin), S))).astype(S.dtype)
     if top_db is not None:
-        log_spec = np.maximum(log_spec, log_spec.max() - np.float32(top_db))
+        log_spec = np.maximum(log_spec, log_spec.max() - dt(top_db))
     return log_spec
 
 
-def mfcc_22k(y: np.ndarray) -> np.ndarray:
-    """librosa.feature.mfcc(y=y, sr=22050) -> float32 [20, T]."""
-    S = power_spectrogram(y)
-    mel = mel_filterbank() @ S  # float32 sgemm in the reference
+def mfcc_22k(y: np.ndarray, dtype=np.float32) -> np.ndarray:
+    """librosa.feature.mfcc(y=y, sr=22050) -> [20, T] in ``dtype`` (float32 clean path, float64 noisy path).
+
+    The DCT is evaluated in float64 and rounded once; scipy.fftpack.dct ran in the input dtype, the
+    difference is bounded in tests/test_oracle_cpu.py::test_oracle_rounding_budget."""
+    S = power_spectrogram(y, dtype)
+    mel = mel_filterbank().astype(dtype) @ S  # float32 sgemm in the reference's clean path
     db = power_to_db(mel)
-    return (dct_matrix() @ db.astype(np.float64)).astype(np.float32)
+    return (dct_matrix() @ db.astype(np.float64)).astype(dtype)
 
 
 def fix_frames(m: np.ndarray, utterance_length: int) -> np.ndarray:
@@ -260,37 +315,29 @@ def fix_frames(m: np.ndarray, utterance_length: int) -> np.ndarray:
     return np.pad(m, ((0, 0), (0, utterance_length - m.shape[1])), mode="constant", constant_values=0)
 
 
-def extract_features_wave(x: np.ndarray, sr_in: int = 16000, utterance_length: int = STANDARD_UTTERANCE_LENGTH) -> np.ndarray:
+def librosa_load_resample(x: np.ndarray, sr_in: int, fast: bool = False) -> np.ndarray:
+    """librosa.load's resampling step: resampy.resample then librosa.resample's
+    ``util.fix_length(y_hat, int(np.ceil(n * ratio)))`` (resampy yields int(n * ratio) samples; when
+    n * ratio is not an integer librosa appends one zero sample)."""
+    x = np.asarray(x, dtype=np.float32)
+    if sr_in == SR_TARGET:
+        return x.copy()
+    y = resample_kaiser_best_fast(x, sr_in, SR_TARGET) if (fast and sr_in < SR_TARGET) else resample_kaiser_best(x, sr_in, SR_TARGET)
+    n_fixed = int(np.ceil(x.shape[0] * (float(SR_TARGET) / float(sr_in))))
+    if len(y) < n_fixed:
+        y = np.pad(y, (0, n_fixed - len(y)))
+    return y[:n_fixed]
+
+
+def extract_features_wave(x: np.ndarray, sr_in: int = 16000, utterance_length: int = STANDARD_UTTERANCE_LENGTH, fast: bool = False) -> np.ndarray:
     """extract_features() for an in-memory mono float waveform at ``sr_in``. -> float32 [20, L]."""
-    y = resample_kaiser_best(np.asarray(x, dtype=np.float32), sr_in, SR_TARGET)
+    y = librosa_load_resample(x, sr_in, fast)
     return fix_frames(mfcc_22k(y), utterance_length)
 
 
-def compute_mfcc_batch(waves: np.ndarray, sr_in: int = 16000, utterance_length: int = STANDARD_UTTERANCE_LENGTH) -> np.ndarray:
+def compute_mfcc_batch(waves: np.ndarray, sr_in: int = 16000, utterance_length: int = STANDARD_UTTERANCE_LENGTH, fast: bool = False) -> np.ndarray:
     """compute_mfcc_all_files() on an in-memory batch [N, n]: per-clip loop, flatten coeff-major, float64 [N, 20*L]."""
     out = np.zeros((len(waves), N_MFCC * utterance_length))
     for i in range(len(waves)):
-        out[i] = extract_features_wave(waves[i], sr_in, utterance_length).flatten()
+        out[i] = extract_features_wave(waves[i], sr_in, utterance_length, fast).flatten()
     return out
-
-
-def synth_clips(n: int, seed: int = 1234, n_samples: int = 16000, sr: int = 16000):
-    """Deterministic synthetic 'spoken digit' clips: formant-like triples per class.
-
-    Returns (waves float32 [n, n_samples], labels int32 [n])."""
-    rng = np.random.default_rng(seed)
-    labels = rng.integers(0, 10, size=n).astype(np.int32)
-    base = np.array([[270, 2290, 3010], [390, 1990, 2550], [530, 1840, 2480], [660, 1720, 2410], [730, 1090, 2440],
-                     [570, 840, 2410], [440, 1020, 2240], [300, 870, 2240], [640, 1190, 2390], [490, 1350, 1690]], dtype=np.float64)
-    t = np.arange(n_samples) / sr
-    waves = np.zeros((n, n_samples), dtype=np.float32)
-    for i in range(n):
-        f = base[labels[i]] * (1.0 + 0.03 * rng.standard_normal(3))
-        amp = rng.uniform(0.1, 0.5)
-        onset = rng.uniform(0.03, 0.06)
-        dur = rng.uniform(0.35, 0.6)
-        env = np.clip((t - onset) / 0.02, 0, 1) * np.clip((onset + dur - t) / 0.05, 0, 1)
-        s = sum(a * np.sin(2 * np.pi * fj * t + rng.uniform(0, 2 * np.pi)) for a, fj in zip((1.0, 0.5, 0.25), f))
-        w = amp * env * s / 1.75 + 0.01 * rng.standard_normal(n_samples)
-        waves[i] = np.clip(w, -1, 1).astype(np.float32)
-    return waves, labels

@@ -32,7 +32,11 @@ def standard_scaler_fit(all_data: np.ndarray):
     mean = all_data.mean(axis=0)
     var = all_data.var(axis=0)
     scale = np.sqrt(var)
-    scale[scale < 10 * np.finfo(np.float64).eps] = 1.0
+    # sklearn >= 1.0 _handle_zeros_in_scale + _is_constant_feature: (near-)constant columns keep scale 1
+    n = all_data.shape[0]
+    eps = np.finfo(np.float64).eps
+    constant = var <= n * eps * var + (n * mean * eps) ** 2
+    scale[(scale < 10 * eps) | constant] = 1.0
     return mean, scale
 
 
@@ -167,7 +171,11 @@ def forward_backward(spec, p: Params, x, y_onehot, masks=None, training=True, ne
             c["mask"] = masks[l]
         cache.append(c)
     prob = softmax(logits)
-    loss = float(-(y_onehot * np.log(np.maximum(prob, 1e-300))).sum(axis=1).mean())
+    # Keras recovers the logits behind the softmax op and uses the log-softmax form, which stays finite
+    # when a probability underflows (log(prob) gave 0 * -inf = NaN in float32).
+    zs = logits - logits.max(axis=1, keepdims=True)
+    logp = zs - np.log(np.exp(zs).sum(axis=1, keepdims=True))
+    loss = float(-(np.where(y_onehot != 0, y_onehot * logp, 0.0)).sum(axis=1).mean())
     g = (prob - y_onehot) / B
     dW = [None] * L; db = [None] * L; dgamma = [None] * L; dbeta = [None] * L
     dx = None

@@ -1,0 +1,142 @@
+"""GPU parity: K4 sign step, FGSM / PGD through the ART-shaped classes, against oracle.attacks_ref,
+plus the device noise models (statistical: the reference draws from NumPy's unseeded global RNG).
+
+The attack iterates x <- x0 + clip(x + a*sign(g) - x0): a sign flip of one gradient component moves
+that component by 2a, so parity is stated as (i) identical sign pattern on components whose float64
+gradient magnitude is above fp32 noise and (ii) identical adversarial points wherever (i) holds.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import build_model, dev, load_params
+from oracle import attacks_ref as A, mlp_ref as P
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(seed=4):
+    spec = P.vd_constrained_spec()
+    p = P.init_params(spec, seed=seed, dtype=np.float32, nonneg_init=False)
+    rng = np.random.default_rng(seed)
+    for l, s in enumerate(spec):
+        if s.bn:
+            p.gamma[l] = (1 + 0.2 * rng.standard_normal(s.n_out)).astype(np.float32)
+            p.mov_mean[l] = (0.2 * rng.standard_normal(s.n_out)).astype(np.float32)
+            p.mov_var[l] = rng.uniform(0.5, 1.5, s.n_out).astype(np.float32)
+    m = build_model(spec)
+    load_params(m, p)
+    return spec, p, m
+
+
+def test_sign_step_kernel(cuda):
+    from lipasr.attacks import sign_step
+
+    rng = np.random.default_rng(0)
+    x0 = rng.standard_normal((37, 880)).astype(np.float32)
+    xa = (x0 + rng.uniform(-0.3, 0.3, x0.shape)).astype(np.float32)
+    g = rng.standard_normal(x0.shape).astype(np.float32)
+    g[0, :5] = [0.0, -0.0, np.nan, np.inf, -np.inf]
+    for alpha, eps in [(0.1, 0.25), (0.3, np.inf), (0.0, 0.1)]:
+        t = dev(xa)
+        sign_step(t, dev(x0), dev(g), alpha, eps)
+        gz = np.where(np.isnan(g), 0.0, g)
+        ref = A.sign_step(xa, x0, gz, np.float32(alpha), np.float32(eps)) if np.isfinite(eps) else xa + np.float32(alpha) * np.sign(gz)
+        np.testing.assert_array_equal(t.cpu().numpy(), ref.astype(np.float32))
+
+
+def test_input_gradient_matches_oracle(cuda):
+    from lipasr.attacks import TensorFlowV2Classifier
+
+    spec, p, m = _setup()
+    clf = TensorFlowV2Classifier(model=m, nb_classes=10, input_shape=(880,), loss_object=None)
+    x = np.random.default_rng(1).standard_normal((96, 880)).astype(np.float32)
+    y = P.to_categorical(np.arange(96) % 10, 10)
+    got = clf.loss_gradient(x, y)
+    ref = P.input_gradient_infer(spec, p.astype(np.float64), x.astype(np.float64), y.astype(np.float64))
+    assert np.abs(got - ref).max() / np.abs(ref).max() < 5e-5
+    np.testing.assert_allclose(clf.predict(x), P.forward_infer(spec, p.astype(np.float64), x.astype(np.float64)), atol=2e-5)
+
+
+@pytest.mark.parametrize("eps", [0.01, 0.3, 1.0, 30.0])
+def test_fgsm_reference_eps_grid(cuda, eps):
+    from lipasr.attacks import FastGradientMethod, TensorFlowV2Classifier
+
+    spec, p, m = _setup()
+    clf = TensorFlowV2Classifier(model=m, nb_classes=10, input_shape=(880,))
+    x = np.random.default_rng(2).standard_normal((70, 880)).astype(np.float32)
+    atk = FastGradientMethod(estimator=clf, eps=eps)
+    adv = atk.generate(x=x)
+    assert adv is not x and adv.dtype == x.dtype and adv.shape == x.shape
+    p64 = p.astype(np.float64)
+    ylab = A._own_labels(spec, p64, x.astype(np.float64), 32)
+    g = np.concatenate([P.input_gradient_infer(spec, p64, x[i:i + 32].astype(np.float64), ylab[i:i + 32]) for i in range(0, 70, 32)])
+    ref = x + np.float32(eps) * np.sign(g).astype(np.float32)
+    solid = np.abs(g) > 1e-4 * np.abs(g).max()
+    assert solid.mean() > 0.99
+    np.testing.assert_array_equal(adv[solid], ref[solid])
+    assert np.abs(adv - x).max() <= eps * (1 + 1e-6) + 1e-6  # no component moves by more than eps
+
+
+@pytest.mark.parametrize("max_iter,eps", [(20, 0.5), (100, 1.0)])
+def test_pgd_matches_oracle(cuda, max_iter, eps):
+    from lipasr.attacks import ProjectedGradientDescent, TensorFlowV2Classifier
+
+    spec, p, m = _setup(seed=6)
+    clf = TensorFlowV2Classifier(model=m, nb_classes=10, input_shape=(880,))
+    x = np.random.default_rng(3).standard_normal((40, 880)).astype(np.float32)
+    atk = ProjectedGradientDescent(estimator=clf, eps=eps, max_iter=max_iter)
+    assert atk.eps_step == 0.1 and atk.batch_size == 32  # ART defaults the reference relies on
+    adv = atk.generate(x=x)
+    assert np.abs(adv - x).max() <= eps + 1e-5
+    ref = A.pgd(spec, p.astype(np.float64), x.astype(np.float64), eps, 0.1, max_iter, 32)
+    # trajectories coincide except where a near-zero gradient component flips sign in fp32
+    agree = np.abs(adv - ref) < 1e-4
+    assert agree.mean() > 0.97, agree.mean()
+    # and the attack is as strong: loss at the adversarial points matches the oracle's
+    p64 = p.astype(np.float64)
+    y = A._own_labels(spec, p64, x.astype(np.float64), 32)
+    def loss(z):
+        return P.forward_backward(spec, p64, z.astype(np.float64), y, training=False)["loss"]
+    assert abs(loss(adv) - loss(ref)) < 2e-2 * max(1.0, abs(loss(ref)))
+    assert loss(adv) > loss(x)
+
+
+def test_generate_leaves_input_untouched_and_handles_tensors(cuda):
+    from lipasr.attacks import FastGradientMethod, TensorFlowV2Classifier
+
+    spec, p, m = _setup()
+    clf = TensorFlowV2Classifier(model=m, nb_classes=10, input_shape=(880,))
+    xt = dev(np.random.default_rng(9).standard_normal((33, 880)))
+    keep = xt.clone()
+    adv = FastGradientMethod(estimator=clf, eps=0.2).generate(x=xt)
+    assert torch.equal(xt, keep) and adv.is_cuda and adv.data_ptr() != xt.data_ptr()
+    with pytest.raises(TypeError):
+        FastGradientMethod(estimator=m, eps=0.1)
+    with pytest.raises(ValueError):
+        TensorFlowV2Classifier(model=m, nb_classes=11, input_shape=(880,))
+
+
+def test_device_noise_statistics(cuda):
+    from lipasr.attacks import add_noise, add_white_noise, add_white_noise_with_snr, noisy_audio_to_mfcc
+    from lipasr.synth import synth_clips
+    from oracle import mfcc_ref as M
+
+    z = torch.zeros(8, 22050, device="cuda")
+    n = add_white_noise(z, 0.05, seed=1)
+    assert abs(float(n.std()) - 0.05) < 5e-4 and abs(float(n.mean())) < 5e-4 and torch.equal(z, torch.zeros_like(z))
+    assert not torch.equal(n[0], n[1]) and torch.equal(n, add_white_noise(z, 0.05, seed=1))
+    mix = add_noise(z, 0.01, 0.002, seed=2).double()
+    frac = 0.0079787
+    assert abs(float(mix.var()) - ((1 - frac) * 0.002 ** 2 + frac * 0.02 ** 2)) < 4e-7
+    t = torch.arange(22050, device="cuda") * 0.01
+    sig = torch.sin(t)[None, :].repeat(4, 1).contiguous()
+    noisy = add_white_noise_with_snr(sig, 10.0, seed=3)
+    snr = 10 * torch.log10((sig ** 2).mean(dim=1) / ((noisy - sig) ** 2).mean(dim=1))
+    assert float((snr - 10.0).abs().max()) < 0.2
+    # sigma = 0 path of black_box_attack_on_audio is the clean MFCC
+    waves, _ = synth_clips(6, seed=8)
+    clean = noisy_audio_to_mfcc(waves, 16000, sigma=0).cpu().numpy()
+    assert np.abs(clean - M.compute_mfcc_batch(waves)).max() < 2e-2
+    loud = noisy_audio_to_mfcc(waves, 16000, sigma=0.05, seed=4).cpu().numpy()
+    assert np.abs(loud - clean).max() > 1.0

@@ -1,0 +1,221 @@
+"""GPU parity: K2 (fp32 MFMA GEMM, BatchNorm, dropout, softmax-CE) and K5 (Adam + NonNeg) against
+oracle.mlp_ref evaluated in float64.
+
+Tolerances: the HIP path is exact-fp32 fma chains (v_mfma_f32_32x32x2_f32) in a different summation
+order than the oracle; activations/gradients agree to ~1e-5 relative to the tensor's max, logits to
+well inside BASELINE's 1e-3 relative bound with identical argmax.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from golden import inputs
+from helpers import build_model, dev, grads_of, load_params, read_params, rel_err
+from oracle import mlp_ref as P
+
+pytestmark = pytest.mark.gpu
+
+
+def _gemm(a, b, ta, tb):
+    from lipasr import _native as N
+
+    h = N.get_handle(0)
+    A = dev(a.T if ta else a)
+    B = dev(b.T if tb else b)
+    M, K = a.shape
+    Nn = b.shape[1]
+    out = torch.full((M, Nn), float("nan"), device="cuda")
+    N.check(N.lib.lipasr_gemm_f32(h.h, int(ta), int(tb), M, Nn, K, N.ptr(A), A.shape[1], N.ptr(B), B.shape[1], N.ptr(out), Nn, N.stream_ptr()))
+    return out.cpu().numpy()
+
+
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("shape", [(512, 1024, 880), (182, 10, 64), (64, 10, 182), (33, 47, 21), (1, 1, 1), (512, 880, 10), (880, 1024, 512)])
+def test_gemm_all_layouts(cuda, ta, tb, shape):
+    M, N_, K = shape
+    rng = np.random.default_rng(M + 7 * N_ + 13 * K)
+    a = rng.standard_normal((M, K)).astype(np.float32)
+    b = rng.standard_normal((K, N_)).astype(np.float32)
+    # asymmetric integer check first: catches a transposed C map exactly
+    ai = rng.integers(-3, 4, (M, K)).astype(np.float32)
+    bi = rng.integers(-3, 4, (K, N_)).astype(np.float32)
+    np.testing.assert_array_equal(_gemm(ai, bi, ta, tb), ai.astype(np.float64) @ bi.astype(np.float64))
+    ref = a.astype(np.float64) @ b.astype(np.float64)
+    bound = 4e-7 * (np.abs(a).astype(np.float64) @ np.abs(b).astype(np.float64)) + 1e-30
+    assert np.all(np.abs(_gemm(a, b, ta, tb) - ref) <= bound)
+
+
+def test_gemm_rejects_bad_arguments(cuda):
+    from lipasr import _native as N
+
+    h = N.get_handle(0)
+    t = torch.zeros(4, 4, device="cuda")
+    assert N.lib.lipasr_gemm_f32(h.h, 0, 0, 4, 4, 0, N.ptr(t), 4, N.ptr(t), 4, N.ptr(t), 4, N.stream_ptr()) == N.EINVAL
+    assert N.lib.lipasr_gemm_f32(h.h, 0, 0, 4, 4, 4, None, 4, N.ptr(t), 4, N.ptr(t), 4, N.stream_ptr()) == N.EINVAL
+    assert N.lib.lipasr_gemm_f32(h.h, 0, 0, 4, 4, 4, N.ptr(t), 2, N.ptr(t), 4, N.ptr(t), 4, N.stream_ptr()) == N.EINVAL
+
+
+def test_small_case_against_golden(cuda, golden_dir):
+    from golden.make_golden import spec_from
+
+    g = np.load(os.path.join(golden_dir, "mlp.npz"))
+    spec = spec_from(inputs.MLP_SMALL)
+    p = P.init_params(spec, seed=5, dtype=np.float32, nonneg_init=True)
+    m = build_model(spec, max_batch=64)
+    load_params(m, p)
+    x, y, masks = inputs.mlp_small_case()
+    xt, yt = dev(x), dev(y)
+    mt = [dev(k) if k is not None else None for k in masks]
+    probs = torch.zeros(8, 10, device="cuda")
+    m.train_fwd_bwd(xt, yt, masks=mt, probs=probs)
+    got = grads_of(m, spec)
+    for l in range(3):
+        assert rel_err(got["dW"][l], g[f"dW{l}"]) < 2e-5
+        assert rel_err(got["db"][l], g[f"db{l}"]) < 2e-5
+        if spec[l].bn:
+            assert rel_err(got["dgamma"][l], g[f"dgamma{l}"]) < 2e-5
+            assert rel_err(got["dbeta"][l], g[f"dbeta{l}"]) < 2e-5
+    assert abs(float(m._loss_rows[:8].mean()) - float(g["loss"])) < 1e-5
+    m.apply_adam()
+    after = read_params(m, spec)
+    for l in range(3):
+        assert rel_err(after.W[l], g[f"W{l}_after"]) < 1e-5
+        assert rel_err(after.b[l], g[f"b{l}_after"]) < 1e-5 or np.abs(g[f"b{l}_after"]).max() < 1e-2
+        if spec[l].bn:
+            assert rel_err(after.mov_mean[l], g[f"mm{l}_after"]) < 1e-5
+            assert rel_err(after.mov_var[l], g[f"mv{l}_after"]) < 1e-5
+    assert int(m._step.item()) == 1
+    np.testing.assert_allclose(m.predict(x), P.softmax(g["infer_logits"]), atol=1e-5)
+
+
+def _random_state(spec, seed):
+    p = P.init_params(spec, seed=seed, dtype=np.float32, nonneg_init=True)
+    rng = np.random.default_rng(seed + 100)
+    for l, s in enumerate(spec):
+        p.b[l] = (0.1 * rng.standard_normal(s.n_out)).astype(np.float32)
+        if s.bn:
+            p.gamma[l] = (1 + 0.2 * rng.standard_normal(s.n_out)).astype(np.float32)
+            p.beta[l] = (0.1 * rng.standard_normal(s.n_out)).astype(np.float32)
+            p.mov_mean[l] = (0.5 + 0.1 * rng.standard_normal(s.n_out)).astype(np.float32)
+            p.mov_var[l] = rng.uniform(0.5, 1.5, s.n_out).astype(np.float32)
+    return p
+
+
+@pytest.mark.parametrize("batch", [512, 182])
+def test_full_model_forward_backward(cuda, batch):
+    spec = P.vd_constrained_spec()
+    p = _random_state(spec, 1)
+    m = build_model(spec)
+    load_params(m, p)
+    rng = np.random.default_rng(batch)
+    x = rng.standard_normal((batch, 880)).astype(np.float32)
+    y = P.to_categorical(rng.integers(0, 10, batch), 10)
+    masks = [((rng.uniform(size=(batch, s.n_out)) > s.dropout) / (1 - s.dropout)).astype(np.float32) if s.dropout > 0 else None for s in spec]
+    m.train_fwd_bwd(dev(x), dev(y), masks=[dev(k) if k is not None else None for k in masks])
+    ref = P.forward_backward(spec, p.astype(np.float64), x.astype(np.float64), y.astype(np.float64), masks=masks, training=True)
+    got = grads_of(m, spec)
+    for l in range(6):
+        assert rel_err(got["dW"][l], ref["dW"][l]) < 5e-5, l
+        assert rel_err(got["db"][l], ref["db"][l]) < 5e-5, l
+        if spec[l].bn:
+            assert rel_err(got["dgamma"][l], ref["dgamma"][l]) < 5e-5, l
+            assert rel_err(got["dbeta"][l], ref["dbeta"][l]) < 5e-5, l
+    assert abs(float(m._loss_rows[:batch].mean()) - ref["loss"]) < 1e-4 * max(1.0, abs(ref["loss"]))
+    pred_ok = (ref["prob"].argmax(1) == y.argmax(1)).astype(np.float32)
+    np.testing.assert_array_equal(m._correct_rows[:batch].cpu().numpy(), pred_ok)
+
+
+def test_inference_logits_2366_clips(cuda):
+    """BASELINE parity statement: per-utterance logits within 1e-3 relative, argmax identical."""
+    spec = P.vd_constrained_spec()
+    p = _random_state(spec, 2)
+    m = build_model(spec)
+    load_params(m, p)
+    x = np.random.default_rng(5).standard_normal((2366, 880)).astype(np.float32)
+    ref = P.forward_infer(spec, p.astype(np.float64), x.astype(np.float64), return_logits=True)
+    got = m.predict_device(dev(x), logits=True).cpu().numpy()
+    rel = np.abs(got - ref).max(axis=1) / np.maximum(np.abs(ref).max(axis=1), 1e-6)
+    assert rel.max() <= 1e-3, rel.max()
+    np.testing.assert_array_equal(got.argmax(1), ref.argmax(1))
+    np.testing.assert_allclose(m.predict(x), P.softmax(ref), atol=2e-5)
+
+
+def test_n_train_steps_track_the_oracle(cuda):
+    """5 optimizer steps (fwd, bwd, Adam, NonNeg, BN moving statistics) with injected dropout masks."""
+    spec = P.vd_constrained_spec()
+    p = _random_state(spec, 3)
+    m = build_model(spec)
+    load_params(m, p)
+    p64 = p.astype(np.float64)
+    st = P.AdamState()
+    rng = np.random.default_rng(11)
+    for step in range(5):
+        bsz = 512 if step < 4 else 182
+        x = rng.standard_normal((bsz, 880)).astype(np.float32)
+        y = P.to_categorical(rng.integers(0, 10, bsz), 10)
+        masks = [((rng.uniform(size=(bsz, s.n_out)) > s.dropout) / (1 - s.dropout)).astype(np.float32) if s.dropout > 0 else None for s in spec]
+        P.train_step(spec, p64, st, x.astype(np.float64), y.astype(np.float64), masks=masks)
+        m.train_on_batch(dev(x), dev(y), masks=[dev(k) if k is not None else None for k in masks])
+    after = read_params(m, spec)
+    for l in range(6):
+        # Adam normalises the update, so after 5 steps every weight moved by <= 5e-3; compare the movement
+        d = np.abs(after.W[l] - p64.W[l])
+        assert np.quantile(d, 0.9999) < 2e-4 and d.max() < 3e-3, (l, np.quantile(d, 0.9999), d.max())
+        assert after.W[l].min() >= 0
+        if spec[l].bn:
+            assert rel_err(after.mov_mean[l], p64.mov_mean[l]) < 1e-4
+            assert rel_err(after.mov_var[l], p64.mov_var[l]) < 1e-4
+            assert np.abs(after.gamma[l] - p64.gamma[l]).max() < 2e-4
+    assert int(m._step.item()) == 5
+
+
+def test_philox_dropout_statistics_and_backward_consistency(cuda):
+    spec = [P.LayerSpec(64, 256, False, 0.4, False), P.LayerSpec(256, 10, False, 0.0, False)]
+    m = build_model(spec, max_batch=1024)
+    x = np.abs(np.random.default_rng(0).standard_normal((1024, 64))).astype(np.float32)
+    y = P.to_categorical(np.zeros(1024, dtype=int), 10)
+    dense = [l for l in m.layers if "dense" in l.name]
+    dense[0].set_weights([np.full((64, 256), 0.01, np.float32), np.ones(256, np.float32)])
+    m.train_fwd_bwd(dev(x), dev(y))
+    from lipasr import _native as N
+    # H of block 0 lives in the plan workspace; recover the mask from dW of layer 1 instead: rows of the mask
+    # are visible through predict-vs-train difference, so check the keep rate via the bias gradient path:
+    g1 = m._grads.clone()
+    m.train_fwd_bwd(dev(x), dev(y))
+    assert torch.equal(g1, m._grads)  # same (seed, step) -> same mask -> bitwise same gradients
+    m.apply_adam()  # step counter advances -> new mask
+    m.train_fwd_bwd(dev(x), dev(y))
+    assert not torch.equal(g1, m._grads)
+    m.train_fwd_bwd(dev(x), dev(y), dropout=False)
+    ref = P.forward_backward(spec, read_params(m, spec), x.astype(np.float64), y.astype(np.float64), training=True)
+    assert rel_err(grads_of(m, spec)["dW"][0], ref["dW"][0]) < 5e-5
+
+
+def test_layer_protocol_and_checkpoint(cuda, tmp_path):
+    from lipasr import keras as K
+
+    spec = P.vd_constrained_spec()
+    m = build_model(spec)
+    names = [l.name for l in m.layers]
+    assert sum("dense" in n for n in names) == 6 and sum("batch" in n for n in names) == 5
+    d0 = [l for l in m.layers if "dense" in l.name][0]
+    w, b = d0.get_weights()
+    assert w.shape == (880, 1024) and w.dtype == np.float32 and b.shape == (1024,)
+    w[0, 0] = 123.0  # caller owns the copy
+    assert d0.get_weights()[0][0, 0] != 123.0
+    lim = np.sqrt(6.0 / (880 + 1024))
+    assert abs(w[1:].max() - lim) < 1e-3 and abs(w[1:].min() + lim) < 1e-3  # glorot_uniform
+    bn = [l for l in m.layers if "batch" in l.name][0].get_weights()
+    assert [a.shape for a in bn] == [(1024,)] * 4 and np.all(bn[0] == 1) and np.all(bn[3] == 1) and np.all(bn[1] == 0)
+    x = np.random.default_rng(0).standard_normal((40, 880)).astype(np.float32)
+    before = m.predict(x)
+    path = str(tmp_path / "ckpt" / "TEST.pt")
+    m.save(path)
+    m2 = K.load_model(path)
+    np.testing.assert_array_equal(m2.predict(x), before)
+    y = P.to_categorical(np.arange(40) % 10, 10)
+    loss, acc = m.evaluate(x, y)
+    assert np.isfinite(loss) and 0 <= acc <= 1

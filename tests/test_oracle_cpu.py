@@ -1,0 +1,289 @@
+"""CPU suite: the oracle against known answers, the committed golden vectors and the reference-held data.
+
+The reference has no tests and no stored outputs for this path and its modules cannot run here
+(TensorFlow / librosa / ART absent), so the oracle is PARITY UNPINNED; what pins it against drift is
+below: mathematical known answers, cross-checks against SciPy, finite differences, and the fixtures
+written by tests/golden/make_golden.py.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import scipy.fft
+import scipy.fftpack
+import scipy.signal
+
+from golden import inputs
+from oracle import attacks_ref as A, constraints_ref as C, mfcc_ref as M, mlp_ref as P
+
+
+# ------------------------------------------------------------------ reference-held data
+def test_reference_label_fixtures(golden_dir):
+    lab = np.load(os.path.join(golden_dir, "ref_labels.npz"))
+    assert lab["train"].shape == (16566,) and lab["dev"].shape == (4733,) and lab["test"].shape == (2366,)
+    for k in ("train", "dev", "test"):
+        assert lab[k].dtype == np.int32
+        hist = np.bincount(lab[k], minlength=10)
+        assert hist.shape == (10,) and hist.min() > 0.8 * hist.mean()  # near-balanced 10 classes
+    meta = json.load(open(os.path.join(golden_dir, "ref_meta.json")))
+    # float64 (16566, 880) + 128-byte npy header
+    assert meta["train_data_npy_bytes"] == 128 + 16566 * 880 * 8
+
+
+def test_feature_layout_is_coeff_major():
+    m = np.arange(20 * 44, dtype=np.float32).reshape(20, 44)
+    flat = m.flatten()
+    assert flat[3 * 44 + 7] == m[3, 7]  # index = coeff*44 + frame (extract_features...py:145-149)
+    assert M.STANDARD_UTTERANCE_LENGTH == 1 + 22050 // 512
+
+
+# ------------------------------------------------------------------ MFCC oracle
+def test_resample_loop_equals_vectorised():
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal(700).astype(np.float32)
+    a = M.resample_kaiser_best(x, 16000, 22050)
+    b = M.resample_kaiser_best_loop(x, 16000, 22050)
+    assert len(a) == int(700 * 22050 / 16000)
+    np.testing.assert_allclose(a, b, rtol=0, atol=2e-6)
+
+
+def test_resample_tone_is_a_tone():
+    t = np.arange(16000) / 16000.0
+    x = np.sin(2 * np.pi * 1000 * t).astype(np.float32)
+    y = M.resample_kaiser_best(x, 16000, 22050)
+    t2 = np.arange(len(y)) / 22050.0
+    mid = slice(200, -200)
+    np.testing.assert_allclose(y[mid], np.sin(2 * np.pi * 1000 * t2)[mid], atol=5e-6)
+
+
+def test_librosa_fix_length():
+    x = np.ones(15999, dtype=np.float32)
+    assert len(M.librosa_load_resample(x, 16000)) == 22049  # resampy gives 22048, librosa pads to ceil
+    x = np.ones(7430, dtype=np.float32)
+    y = M.librosa_load_resample(x, 16000)
+    assert len(y) == 10240 and y[-1] == 0.0
+    assert M.extract_features_wave(x).shape == (20, 44)
+    assert 1 + len(y) // 512 == 21
+
+
+def test_tables_against_scipy():
+    np.testing.assert_allclose(M.hann_periodic(), scipy.signal.get_window("hann", 2048, fftbins=True), atol=1e-15)
+    x = np.random.default_rng(1).standard_normal((128, 5))
+    np.testing.assert_allclose(M.dct_matrix() @ x, scipy.fftpack.dct(x, type=2, norm="ortho", axis=0)[:20], atol=1e-12)
+    fb = M.mel_filterbank()
+    assert fb.shape == (128, 1025) and fb.dtype == np.float32 and fb.min() >= 0
+    assert np.all((fb > 0).sum(axis=1) >= 1)
+    # slaney normalisation: every triangle integrates to ~1 over frequency
+    area = fb.sum(axis=1) * (11025.0 / 1024)
+    np.testing.assert_allclose(area[5:], 1.0, rtol=0.2)
+    assert ((fb > 0).sum(axis=0) <= 2).all()  # at most two filters per bin -> sparse evaluation is exact
+
+
+def test_mfcc_edge_cases():
+    z = M.extract_features_wave(np.zeros(16000, dtype=np.float32))
+    assert z.shape == (20, 44)
+    np.testing.assert_allclose(z[0], -100.0 * np.sqrt(128.0), rtol=1e-6)  # all bins at 10 log10(1e-10)
+    np.testing.assert_allclose(z[1:], 0.0, atol=1e-4)
+    short = M.extract_features_wave(inputs.test_clips()[0][:7430])
+    assert np.all(short[:, 21:] == 0.0) and np.any(short[:, 20] != 0.0)  # literal zero padding of the matrix
+    long = M.extract_features_wave(np.concatenate([inputs.test_clips()[0]] * 2))
+    assert long.shape == (20, 44)
+
+
+def test_oracle_rounding_budget():
+    """Bounds the oracle's own float64-vs-float32 choices: the DCT evaluated in
+    float32 (scipy.fftpack's dtype) and an all-float32 FFT move the features by far less than the
+    standardised-feature budget that the 1e-3 logit tolerance leaves."""
+    clips = inputs.test_clips()
+    worst_dct, worst_fft = 0.0, 0.0
+    for c in clips:
+        y = M.librosa_load_resample(c, 16000)
+        S = M.power_spectrogram(y)
+        db = M.power_to_db(M.mel_filterbank() @ S)
+        ref = M.dct_matrix() @ db.astype(np.float64)
+        f32 = scipy.fftpack.dct(db.astype(np.float32), type=2, norm="ortho", axis=0)[:20]
+        worst_dct = max(worst_dct, np.abs(ref - f32).max())
+        yp = M.reflect_pad(y, 1024)
+        idx = np.arange(2048)[:, None] + 512 * np.arange(S.shape[1])[None, :]
+        fr = (M.hann_periodic().astype(np.float32)[:, None] * yp[idx]).astype(np.float32)
+        S32 = (np.abs(scipy.fft.rfft(fr, axis=0)) ** 2).astype(np.float32)
+        db32 = M.power_to_db(M.mel_filterbank() @ S32)
+        worst_fft = max(worst_fft, np.abs(M.dct_matrix() @ db32.astype(np.float64) - ref).max())
+    assert worst_dct < 2e-3, worst_dct
+    assert worst_fft < 5e-2, worst_fft
+
+
+def test_golden_mfcc(golden_dir):
+    g = np.load(os.path.join(golden_dir, "mfcc.npz"))
+    clips = inputs.test_clips()
+    np.testing.assert_allclose(M.compute_mfcc_batch(clips).astype(np.float32), g["feats"], rtol=0, atol=1e-4)
+    y0 = M.librosa_load_resample(clips[0], 16000)
+    np.testing.assert_allclose(y0[:2048], g["resampled_head"], atol=1e-7)
+
+
+# ------------------------------------------------------------------ constraints oracle
+def test_norm_constraint_known_answer():
+    ws = inputs.nonneg_kernels(inputs.FULL_WIDTHS)
+    out = C.norm_constraint_pass(ws, 10.0)
+    for w in out:
+        assert abs(C.sigma_max(w) - 10.0 ** (1 / 6)) < 2e-6  # 1.4677993
+        assert w.min() >= 0
+
+
+def test_simple_norm_closed_form_and_visits():
+    ws = inputs.nonneg_kernels(inputs.SMALL_WIDTHS)
+    out, norms = C.simple_norm_constraint_pass(ws, 0.1, [])
+    m = len(ws)
+    for k, n in enumerate(norms):
+        assert abs(n - C.simple_norm_closed_form(norms[0], 0.1, m, k)) / n < 1e-5
+    # listed indices: visited last-to-first, once per occurrence
+    out2, norms2 = C.simple_norm_constraint_pass(ws, 0.1, [0, 2, 2])
+    assert len(norms2) == 4
+    np.testing.assert_array_equal(out2[1], ws[1])
+    s = [(0.1 / (n + C.EPS)) ** (1 / m) for n in norms2[:-1]]
+    np.testing.assert_allclose(out2[2], ws[2] * np.float32(s[0]) * np.float32(s[1]), rtol=1e-6)
+    np.testing.assert_allclose(out2[0], ws[0] * np.float32(s[2]), rtol=1e-6)
+
+
+def test_custom_constraint_is_frobenius():
+    w = inputs.signed_kernels([30, 20])[0]
+    out = C.custom_constraint(w, 3.0)
+    assert abs(np.linalg.norm(out) - 3.0) < 1e-5 and out.min() >= 0
+
+
+def test_fista_runs_and_locates_by_value():
+    ws = inputs.nonneg_kernels([24, 16, 12, 6], seed=2)
+    out = C.fista_pass(ws, 5.0, 2)
+    assert [o.shape for o in out] == [w.shape for w in ws]
+    assert all(o.dtype == np.float32 and o.min() >= 0 for o in out)
+    dup = [ws[0], ws[1], ws[1].copy()[:, :12] if False else ws[2]]
+    first = C.fista_projection(ws[1], ws, 5.0, 2)
+    np.testing.assert_allclose(first, C.fista_projection(ws[1].copy(), dup[:2] + [ws[2]], 5.0, 2))
+
+
+def test_lipschitz_readouts():
+    ws = inputs.nonneg_kernels(inputs.SMALL_WIDTHS)
+    norms = C.get_norms(ws)
+    assert C.get_upper_lipschitz(norms) >= C.sigma_max(C.product_chain(ws)) * (1 - 1e-6)
+    bn = [(np.full(64, 2.0), np.full(64, 9.0)), (np.full(32, 1.0), np.full(32, 4.0))]
+    assert abs(C.get_lipschitz_constrained(ws, bn) - C.sigma_max(C.product_chain(ws)) / (1.5 * 2.0)) < 1e-6
+
+
+def test_golden_constraints(golden_dir):
+    g = np.load(os.path.join(golden_dir, "constraints.npz"))
+    ws = inputs.nonneg_kernels(inputs.SMALL_WIDTHS)
+    for i, w in enumerate(C.norm_constraint_pass(ws, 10.0)):
+        np.testing.assert_allclose(w, g[f"nc_{i}"], rtol=1e-6)
+    out, norms = C.simple_norm_constraint_pass(ws, 0.1, [])
+    np.testing.assert_allclose(norms, g["sn_norms"], rtol=1e-6)
+    for i, w in enumerate(out):
+        np.testing.assert_allclose(w, g[f"sn_{i}"], rtol=1e-6)
+
+
+# ------------------------------------------------------------------ MLP oracle
+def _fd_check(training):
+    spec = [P.LayerSpec(12, 9, True, 0.0, True), P.LayerSpec(9, 7, False, 0.0, True), P.LayerSpec(7, 4, False, 0.0, True)]
+    p = P.init_params(spec, seed=1, dtype=np.float64)
+    for l in range(2):
+        if p.gamma[l] is not None:
+            p.gamma[l] = p.gamma[l] * 1.3
+            p.mov_var[l] = p.mov_var[l] * 0.7
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((6, 12))
+    y = P.to_categorical(rng.integers(0, 4, 6), 4).astype(np.float64)
+    out = P.forward_backward(spec, p, x, y, training=training, need_dx=True)
+
+    def loss_at(pp, xx):
+        return P.forward_backward(spec, pp, xx, y, training=training)["loss"]
+
+    eps = 1e-6
+    for l in range(3):
+        for idx in [(0, 0), (3, 2)]:
+            pp = p.copy(); pp.W[l][idx] += eps
+            pm = p.copy(); pm.W[l][idx] -= eps
+            fd = (loss_at(pp, x) - loss_at(pm, x)) / (2 * eps)
+            assert abs(fd - out["dW"][l][idx]) < 1e-6 + 1e-4 * abs(fd)
+    xp = x.copy(); xp[2, 5] += eps
+    xm = x.copy(); xm[2, 5] -= eps
+    fd = (loss_at(p, xp) - loss_at(p, xm)) / (2 * eps)
+    assert abs(fd - out["dx"][2, 5]) < 1e-6 + 1e-4 * abs(fd)
+
+
+def test_finite_differences_train():
+    _fd_check(True)
+
+
+def test_finite_differences_infer():
+    _fd_check(False)
+
+
+def test_loss_is_finite_in_float32_with_saturated_logits():
+    spec = P.vd_constrained_spec()
+    p = P.init_params(spec, seed=0, dtype=np.float32, nonneg_init=True)
+    rng = np.random.default_rng(0)
+    x = (5 * rng.standard_normal((16, 880))).astype(np.float32)
+    y = P.to_categorical(rng.integers(0, 10, 16), 10)
+    out = P.forward_backward(spec, p, x, y, training=True)
+    assert np.isfinite(out["loss"])
+
+
+def test_adam_matches_keras_form():
+    w = np.array([1.0, -2.0]); g = np.array([0.5, -0.25]); m = np.zeros(2); v = np.zeros(2)
+    P.adam_update(w, g, m, v, 1)
+    lr_t = 1e-3 * np.sqrt(1 - 0.999) / (1 - 0.9)
+    np.testing.assert_allclose(w, np.array([1.0, -2.0]) - lr_t * (0.1 * g) / (np.sqrt(0.001 * g * g) + 1e-7), rtol=1e-12)
+
+
+def test_scaler_constant_columns():
+    x = np.random.default_rng(0).standard_normal((50, 4))
+    x[:, 1] = 3.0
+    x[:, 2] = 1e8 + 1e-9 * np.arange(50)  # round-off variance only
+    mean, scale = P.standard_scaler_fit(x)
+    assert scale[1] == 1.0 and scale[2] == 1.0 and abs(scale[0] - x[:, 0].std()) < 1e-12
+
+
+def test_shuffle_structure():
+    b = P.tf_shuffle_batches(2000, 512, buffer_size=880, seed=1)
+    order = np.concatenate(b)
+    assert sorted(order) == list(range(2000)) and [len(x) for x in b] == [512, 512, 512, 464]
+    assert all(order[i] < i + 880 for i in range(2000))
+
+
+def test_golden_mlp(golden_dir):
+    from golden.make_golden import spec_from
+
+    g = np.load(os.path.join(golden_dir, "mlp.npz"))
+    spec = spec_from(inputs.MLP_SMALL)
+    p = P.init_params(spec, seed=5, dtype=np.float32, nonneg_init=True).astype(np.float64)
+    x, y, masks = inputs.mlp_small_case()
+    fb = P.forward_backward(spec, p, x.astype(np.float64), y.astype(np.float64), masks=masks, training=True, need_dx=True)
+    np.testing.assert_allclose(fb["logits"], g["logits"], rtol=1e-10)
+    np.testing.assert_allclose(fb["dW"][0], g["dW0"], rtol=1e-9, atol=1e-14)
+
+
+# ------------------------------------------------------------------ attacks oracle
+def test_pgd_stays_in_eps_ball_and_steps():
+    spec = [P.LayerSpec(10, 8, True, 0.0, False), P.LayerSpec(8, 3, False, 0.0, False)]
+    p = P.init_params(spec, seed=2, dtype=np.float64)
+    x = np.random.default_rng(3).standard_normal((5, 10))
+    adv1 = A.fgsm(spec, p, x, 0.3, batch_size=2)
+    assert np.all(np.isin(np.round(np.abs(adv1 - x), 12), [0.0, 0.3]))
+    adv = A.pgd(spec, p, x, eps=0.25, eps_step=0.1, max_iter=7, batch_size=2)
+    assert np.abs(adv - x).max() <= 0.25 + 1e-12
+    one = A.pgd(spec, p, x, eps=10.0, eps_step=0.1, max_iter=1, batch_size=5)
+    np.testing.assert_allclose(one, A.fgsm(spec, p, x, 0.1, batch_size=5), atol=1e-12)
+    np.testing.assert_allclose(A.sign_step(x, x, np.ones_like(x), 0.1, np.inf), x + 0.1)
+
+
+def test_noise_models_statistics():
+    rng = np.random.default_rng(0)
+    x = np.zeros(200000)
+    assert abs(A.add_white_noise(x, 0.05, rng).std() - 0.05) < 1e-3
+    n = A.add_noise(x, 0.01, 0.002, rng)
+    frac = 2 * (0.5 - 0.49601)  # P(|N(0,1)| < 0.01) ~ 0.00798
+    assert abs(n.var() - ((1 - frac) * 0.002 ** 2 + frac * 0.02 ** 2)) < 2e-7
+    sig = np.sin(np.arange(200000) * 0.01)
+    noisy = A.add_white_noise_with_snr(sig, 10.0, rng)
+    snr = 10 * np.log10(np.mean(sig ** 2) / np.mean((noisy - sig) ** 2))
+    assert abs(snr - 10.0) < 0.1

@@ -1,0 +1,189 @@
+"""GPU parity: K3 Lipschitz projections (HIP) against oracle.constraints_ref (LAPACK SVD on the host).
+
+Tolerances: sigma and projected kernels agree to 2e-5 relative.  The HIP path sums in fp32 with a
+different association than LAPACK and takes sigma from a Gram eigenvalue (product) or a converged
+power iteration (per layer); the reference's own float32 SVD is good to ~1e-6.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from golden import inputs
+from helpers import dev, rel_err
+from oracle import constraints_ref as R
+
+pytestmark = pytest.mark.gpu
+RTOL = 2e-5
+
+
+class FakeLayer:
+    """The 10-line duck-typed layer protocol of Constraints.py: name / get_weights / set_weights."""
+
+    def __init__(self, name, w, b=None):
+        self.name, self.w, self.b = name, np.array(w, dtype=np.float32), np.zeros(w.shape[1], np.float32) if b is None else b
+
+    def get_weights(self):
+        return [self.w.copy(), self.b.copy()]
+
+    def set_weights(self, ws):
+        self.w, self.b = np.array(ws[0], dtype=np.float32), np.array(ws[1], dtype=np.float32)
+
+
+class FakeModel:
+    def __init__(self, ws):
+        self.layers = []
+        for i, w in enumerate(ws):
+            self.layers.append(FakeLayer("dense" if i == 0 else f"dense_{i}", w))
+            if i < len(ws) - 1:  # a non-dense layer in between, as Dropout sits in the reference model
+                self.layers.append(type("Drop", (), {"name": f"dropout_{i}", "get_weights": lambda self: []})())
+
+
+@pytest.mark.parametrize("widths", [inputs.SMALL_WIDTHS, inputs.FULL_WIDTHS, [50, 20], [33, 17, 5]])
+@pytest.mark.parametrize("rho", [0.1, 10.0])
+def test_simple_norm_constraint_all_layers(cuda, widths, rho):
+    from lipasr.Constraints import simple_norm_constraint
+
+    ws = inputs.nonneg_kernels(widths)
+    ref, norms = R.simple_norm_constraint_pass(ws, rho, [])
+    model = FakeModel(ws)
+    cb = simple_norm_constraint(rho, [])
+    cb.set_model(model)
+    cb.on_batch_end(0)
+    got_norms = cb.last_norms.cpu().numpy()
+    np.testing.assert_allclose(got_norms, norms, rtol=RTOL)
+    for l, r in zip([l for l in model.layers if "dense" in l.name], ref):
+        assert rel_err(l.w, r) < RTOL
+    # closed form of SURVEY 3.1
+    m = len(ws)
+    for k, n in enumerate(got_norms):
+        assert abs(n - R.simple_norm_closed_form(norms[0], rho, m, k)) / n < 5e-5
+
+
+def test_simple_norm_constraint_listed_indices_and_signed_kernels(cuda):
+    from lipasr.Constraints import simple_norm_constraint
+
+    ws = inputs.signed_kernels(inputs.SMALL_WIDTHS)
+    for idx in ([1], [0, 2, 2], [2, 0]):
+        ref, norms = R.simple_norm_constraint_pass(ws, 0.1, idx)
+        model = FakeModel(ws)
+        cb = simple_norm_constraint(0.1, idx)
+        cb.set_model(model)
+        cb.on_batch_end(0)
+        np.testing.assert_allclose(cb.last_norms.cpu().numpy(), norms, rtol=RTOL)
+        for l, r in zip([l for l in model.layers if "dense" in l.name], ref):
+            assert rel_err(l.w, r) < RTOL
+        # get_projection keeps the reference's signature: one kernel in, scaled kernel out
+        model2 = FakeModel(ws)
+        cb.set_model(model2)
+        np.testing.assert_allclose(cb.get_projection(ws[1]), R.simple_norm_projection(ws[1], ws, 0.1), rtol=RTOL)
+
+
+def test_product_norm_golden_and_zero(cuda, golden_dir):
+    from lipasr.extract_features_construct_dataset import get_lipschitz_constrained, product_norm
+
+    g = np.load(os.path.join(golden_dir, "constraints.npz"))
+    ws = inputs.nonneg_kernels(inputs.SMALL_WIDTHS)
+    model = FakeModel(ws)
+    assert abs(float(product_norm(model).item()) - g["sn_norms"][0]) / g["sn_norms"][0] < RTOL
+    zero = FakeModel([np.zeros_like(w) for w in ws])
+    assert float(product_norm(zero).item()) == 0.0
+    assert abs(get_lipschitz_constrained(FakeModel(ws)) - R.get_lipschitz_constrained(ws, [])) / g["sn_norms"][0] < RTOL
+
+
+@pytest.mark.parametrize("widths", [inputs.SMALL_WIDTHS, inputs.FULL_WIDTHS])
+def test_norm_constraint_cold_then_warm(cuda, widths, golden_dir):
+    from lipasr.Constraints import norm_constraint
+
+    rho = 10.0
+    ws = inputs.nonneg_kernels(widths)
+    model = FakeModel(ws)
+    cb = norm_constraint(rho)
+    cb.set_model(model)
+    cb.on_train_begin()
+    assert cb.m == len(ws)
+    cb.on_batch_end(0)  # cold start: 48 round trips
+    ref = R.norm_constraint_pass(ws, rho)
+    sig = cb.last_sigmas.cpu().numpy()
+    np.testing.assert_allclose(sig, R.get_norms(ws), rtol=RTOL)
+    dense = [l for l in model.layers if "dense" in l.name]
+    for l, r in zip(dense, ref):
+        assert rel_err(l.w, r) < RTOL
+        assert abs(R.sigma_max(l.w) - rho ** (1 / len(ws))) < 5e-5  # every kernel ends at rho^(1/m)
+    if widths == inputs.SMALL_WIDTHS:
+        g = np.load(os.path.join(golden_dir, "constraints.npz"))
+        for i, l in enumerate(dense):
+            assert rel_err(l.w, g[f"nc_{i}"]) < RTOL
+    # perturb (a training step would), then one warm pass of 4 round trips
+    rng = np.random.default_rng(0)
+    for l in dense:
+        l.w = (l.w * (1 + 0.02 * rng.standard_normal(l.w.shape))).astype(np.float32) - np.float32(1e-3)
+    pert = [l.w.copy() for l in dense]
+    cb.on_batch_end(1)
+    ref2 = R.norm_constraint_pass(pert, rho)
+    for l, r in zip(dense, ref2):
+        assert rel_err(l.w, r) < 1e-4
+        assert l.w.min() >= 0
+
+
+def test_sigma_max_signed_matrix(cuda):
+    from lipasr import _native as N
+
+    h = N.get_handle(0)
+    for shape in [(880, 1024), (64, 10), (7, 300)]:
+        rng = np.random.default_rng(shape[0])
+        u, _ = np.linalg.qr(rng.standard_normal((shape[0], min(shape))))
+        v, _ = np.linalg.qr(rng.standard_normal((shape[1], min(shape))))
+        s = np.linspace(3.0, 0.1, min(shape)); s[1] = 2.4  # gap ratio 0.8
+        w = ((u * s) @ v.T).astype(np.float32)
+        wt, vs, out = dev(w), torch.zeros(shape[1], device="cuda"), torch.zeros(1, device="cuda")
+        N.check(N.lib.lipasr_sigma_max(h.h, N.ptr(wt), shape[0], shape[1], N.ptr(vs), 0, 200, 0, N.ptr(out), N.stream_ptr()))
+        assert abs(float(out.item()) - R.sigma_max(w)) / R.sigma_max(w) < RTOL
+
+
+def test_custom_constraint_frobenius(cuda):
+    from lipasr.Constraints import customConstraint
+
+    w = inputs.signed_kernels([880, 1024])[0]
+    c = customConstraint(5.0)
+    assert c.get_config() == {"rho": 5.0}
+    assert rel_err(c(w), R.custom_constraint(w, 5.0)) < 1e-5
+    t = dev(w)
+    out = c(t)
+    assert out.is_cuda and out.data_ptr() != t.data_ptr() and torch.equal(t.cpu(), torch.as_tensor(w))  # pure function
+
+
+def test_fista_surface(cuda):
+    from lipasr.Constraints import norm_constraint_FISTA
+
+    ws = inputs.nonneg_kernels([24, 16, 12, 6], seed=2)
+    model = FakeModel(ws)
+    cb = norm_constraint_FISTA(rho=5.0, nit=2)
+    cb.set_model(model)
+    cb.on_batch_end(0)
+    ref = R.fista_pass(ws, 5.0, 2)
+    for l, r in zip([l for l in model.layers if "dense" in l.name], ref):
+        assert rel_err(l.w, r) < 2e-3  # fp32 products + GPU SVD vs the float64 host iteration
+
+
+def test_lip_readouts_on_native_model(cuda):
+    from helpers import build_model, load_params
+    from lipasr.extract_features_construct_dataset import get_lipschitz_constrained, get_norms, get_upper_lipschitz
+    from oracle import mlp_ref as P
+
+    spec = P.vd_constrained_spec()
+    p = P.init_params(spec, seed=3, dtype=np.float32, nonneg_init=True)
+    rng = np.random.default_rng(1)
+    for l in range(5):
+        p.gamma[l] = (1 + 0.1 * rng.standard_normal(spec[l].n_out)).astype(np.float32)
+        p.mov_var[l] = rng.uniform(0.5, 2.0, spec[l].n_out).astype(np.float32)
+    m = build_model(spec)
+    load_params(m, p)
+    norms = get_norms(m)
+    np.testing.assert_allclose(norms, R.get_norms(p.W), rtol=RTOL)
+    assert abs(get_upper_lipschitz(norms) - R.get_upper_lipschitz(R.get_norms(p.W))) / get_upper_lipschitz(norms) < 1e-4
+    bn = [(p.gamma[l], p.mov_var[l]) for l in range(5)]
+    ref = R.get_lipschitz_constrained(p.W, bn)
+    assert abs(get_lipschitz_constrained(m) - ref) / ref < 5e-5
