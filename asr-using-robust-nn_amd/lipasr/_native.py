@@ -9,6 +9,11 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# PyTorch-ROCm bundles its own HIP runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7).  It must be
+# in the process BEFORE liblipasr.so is opened so that liblipasr's DT_NEEDED libamdhip64.so.7 resolves to
+# that same copy: two HIP runtimes in one process cannot both own the device ("no ROCm-capable device").
+import torch  # noqa: F401  (plumbing: device memory, streams, process groups)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblipasr.so")
 

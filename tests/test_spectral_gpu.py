@@ -136,7 +136,7 @@ def test_sigma_max_signed_matrix(cuda):
         rng = np.random.default_rng(shape[0])
         u, _ = np.linalg.qr(rng.standard_normal((shape[0], min(shape))))
         v, _ = np.linalg.qr(rng.standard_normal((shape[1], min(shape))))
-        s = np.linspace(3.0, 0.1, min(shape)); s[1] = 2.4  # gap ratio 0.8
+        s = np.concatenate([[3.0], np.linspace(2.4, 0.1, min(shape) - 1)])  # gap ratio 0.8
         w = ((u * s) @ v.T).astype(np.float32)
         wt, vs, out = dev(w), torch.zeros(shape[1], device="cuda"), torch.zeros(1, device="cuda")
         N.check(N.lib.lipasr_sigma_max(h.h, N.ptr(wt), shape[0], shape[1], N.ptr(vs), 0, 200, 0, N.ptr(out), N.stream_ptr()))
