@@ -19,165 +19,17 @@ namespace lipasr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum Epi { EPI_STORE = 0, EPI_BIAS = 1, EPI_BIAS_RELU = 2, EPI_BIAS_RELU_BN = 3, EPI_DZ_INFER = 4, EPI_SIGNSTEP = 5 };
-
-struct GemmArgs {
-  const float* A;
-  const float* B;
-  float* C;
-  int M, N, K, lda, ldb, ldc;
-  int epi;
-  const float* bias;
-  const float* gamma;
-  const float* beta;
-  const float* mmean;
-  const float* mvar;
-  float* aux;        // EPI_BIAS_RELU_BN: optional post-ReLU store; EPI_DZ_INFER: post-ReLU activations (read)
-  const float* x0;   // EPI_SIGNSTEP
-  float* x_adv;
-  float alpha, eps;
+enum Epi {
+  EPI_STORE = 0,
+  EPI_BIAS = 1,
+  EPI_BIAS_RELU = 2,
+  EPI_BIAS_RELU_BN = 3,
+  EPI_DZ_INFER = 4,
+  EPI_SIGNSTEP = 5,
+  EPI_BIAS_RELU_STATS = 6,  // training forward: a = relu(acc + b) and per-tile column sums of a, a^2
+  EPI_DH_STATS = 7,         // training backward: g = acc * dropout and per-tile column sums of g, g * xhat
+  EPI_DZ_NOBN = 8           // training backward through Dropout -> ReLU without BatchNorm
 };
-
-// AMODE/BMODE 0: K contiguous in memory (operand(i,k) = P[i*ld + k]); 1: K strided (P[k*ld + i]).
-template <int MODE>
-__device__ __forceinline__ void load_frag(const float* __restrict__ P, int ld, int idx, int kb, int K, bool vec,
-                                          float (&f)[8]) {
-  if (MODE == 0) {
-    const float* p = P + (size_t)idx * ld + kb;
-    if (vec && kb + 8 <= K) {
-      const float4 lo = *reinterpret_cast<const float4*>(p);
-      const float4 hi = *reinterpret_cast<const float4*>(p + 4);
-      f[0] = lo.x; f[1] = lo.y; f[2] = lo.z; f[3] = lo.w;
-      f[4] = hi.x; f[5] = hi.y; f[6] = hi.z; f[7] = hi.w;
-    } else {
-#pragma unroll
-      for (int q = 0; q < 8; ++q) f[q] = (kb + q < K) ? p[q] : 0.0f;
-    }
-  } else {
-#pragma unroll
-    for (int q = 0; q < 8; ++q) f[q] = (kb + q < K) ? P[(size_t)(kb + q) * ld + idx] : 0.0f;
-  }
-}
-
-__device__ __forceinline__ float epilogue_elem(const GemmArgs& g, int gm, int gn, float v) {
-  switch (g.epi) {
-    case EPI_BIAS:
-      return v + g.bias[gn];
-    case EPI_BIAS_RELU:
-      return fmaxf(v + g.bias[gn], 0.0f);
-    case EPI_BIAS_RELU_BN: {
-      const float a = fmaxf(v + g.bias[gn], 0.0f);
-      if (g.aux) g.aux[(size_t)gm * g.ldc + gn] = a;
-      if (g.gamma) return (a - g.mmean[gn]) / sqrtf(g.mvar[gn] + kBnEps) * g.gamma[gn] + g.beta[gn];
-      return a;
-    }
-    case EPI_DZ_INFER: {
-      const float s = g.gamma ? g.gamma[gn] / sqrtf(g.mvar[gn] + kBnEps) : 1.0f;
-      return g.aux[(size_t)gm * g.ldc + gn] > 0.0f ? v * s : 0.0f;
-    }
-    case EPI_SIGNSTEP: {
-      const size_t i = (size_t)gm * g.ldc + gn;
-      const float sg = (v > 0.0f) ? 1.0f : ((v < 0.0f) ? -1.0f : 0.0f);  // NaN -> 0, as ART zeroes NaN gradients
-      const float x0 = g.x0[i];
-      const float xa = g.x_adv[i] + g.alpha * sg;
-      if (isinf(g.eps)) return xa;
-      return x0 + fminf(fmaxf(xa - x0, -g.eps), g.eps);
-    }
-    default:
-      return v;
-  }
-}
-
-template <int AMODE, int BMODE>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) float red[4 * 32 * 32];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 31, h = lane >> 5;
-  const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
-  const int ai = min(m0 + r, g.M - 1);
-  const int bj = min(n0 + r, g.N - 1);
-  const int nch = (g.K + 15) >> 4;
-  const bool vecA = (AMODE == 0) && ((g.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0);
-  const bool vecB = (BMODE == 0) && ((g.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0);
-
-  f32x16 acc;
-#pragma unroll
-  for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
-  float a0[8], b0[8], a1[8], b1[8];
-#pragma unroll
-  for (int q = 0; q < 8; ++q) { a0[q] = b0[q] = a1[q] = b1[q] = 0.0f; }
-
-  int c = wave;
-  if (c < nch) {
-    load_frag<AMODE>(g.A, g.lda, ai, c * 16 + 8 * h, g.K, vecA, a0);
-    load_frag<BMODE>(g.B, g.ldb, bj, c * 16 + 8 * h, g.K, vecB, b0);
-  }
-  while (c < nch) {
-    const int cn = c + 4;
-    if (cn < nch) {
-      load_frag<AMODE>(g.A, g.lda, ai, cn * 16 + 8 * h, g.K, vecA, a1);
-      load_frag<BMODE>(g.B, g.ldb, bj, cn * 16 + 8 * h, g.K, vecB, b1);
-    }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q], b0[q], acc, 0, 0, 0);
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { a0[q] = a1[q]; b0[q] = b1[q]; }
-    c = cn;
-  }
-  // C/D map: col = lane & 31, row = (q & 3) + 8 (q >> 2) + 4 (lane >> 5)
-#pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const int row = (q & 3) + 8 * (q >> 2) + 4 * h;
-    red[wave * 1024 + row * 32 + r] = acc[q];
-  }
-  __syncthreads();
-  const int row = tid >> 3, c4 = (tid & 7) * 4;
-  float4 s = *reinterpret_cast<const float4*>(red + row * 32 + c4);
-#pragma unroll
-  for (int w = 1; w < 4; ++w) {
-    const float4 t = *reinterpret_cast<const float4*>(red + w * 1024 + row * 32 + c4);
-    s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
-  }
-  const int gm = m0 + row;
-  if (gm >= g.M) return;
-  const int gn = n0 + c4;
-  float* crow = (g.epi == EPI_SIGNSTEP ? g.x_adv : g.C) + (size_t)gm * g.ldc;
-  if (gn + 3 < g.N && ((g.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(crow) & 15) == 0)) {
-    float4 o;
-    o.x = epilogue_elem(g, gm, gn, s.x);
-    o.y = epilogue_elem(g, gm, gn + 1, s.y);
-    o.z = epilogue_elem(g, gm, gn + 2, s.z);
-    o.w = epilogue_elem(g, gm, gn + 3, s.w);
-    *reinterpret_cast<float4*>(crow + gn) = o;
-  } else {
-    const float v[4] = {s.x, s.y, s.z, s.w};
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if (gn + e < g.N) crow[gn + e] = epilogue_elem(g, gm, gn + e, v[e]);
-  }
-}
-
-static int launch_gemm(int amode, int bmode, const GemmArgs& g, hipStream_t st) {
-  if (g.M <= 0 || g.N <= 0 || g.K <= 0) {
-    set_error("gemm: empty problem %dx%dx%d", g.M, g.N, g.K);
-    return LIPASR_EINVAL;
-  }
-  const dim3 grid((g.N + 31) / 32, (g.M + 31) / 32);
-  if (amode == 0 && bmode == 0) hipLaunchKernelGGL((gemm_f32_kernel<0, 0>), grid, dim3(256), 0, st, g);
-  else if (amode == 0 && bmode == 1) hipLaunchKernelGGL((gemm_f32_kernel<0, 1>), grid, dim3(256), 0, st, g);
-  else if (amode == 1 && bmode == 0) hipLaunchKernelGGL((gemm_f32_kernel<1, 0>), grid, dim3(256), 0, st, g);
-  else hipLaunchKernelGGL((gemm_f32_kernel<1, 1>), grid, dim3(256), 0, st, g);
-  LP_LAUNCH_CHECK();
-  return LIPASR_OK;
-}
-
-static GemmArgs gemm_args(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
-                          int epi) {
-  GemmArgs g;
-  memset(&g, 0, sizeof(g));
-  g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.epi = epi;
-  return g;
-}
 
 // ---------------------------------------------------------------------------------------------
 // dropout multiplier: 0 or 1/(1-rate), Philox keyed by (seed; element/4, layer, step)
@@ -200,19 +52,362 @@ __device__ __forceinline__ float dropout_mult(const DropArgs& d, int step, size_
   return u > d.rate ? 1.0f / (1.0f - d.rate) : 0.0f;
 }
 
-// column-block helpers: 256 threads = 32 columns x 8 row lanes
-__device__ __forceinline__ float colblock_sum(float x, float (*part)[33], int cx, int ry) {
+
+struct GemmArgs {
+  const float* A;
+  const float* B;
+  float* C;
+  int M, N, K, lda, ldb, ldc;
+  int epi;
+  const float* bias;
+  const float* gamma;
+  const float* beta;
+  const float* mmean;
+  const float* mvar;
+  float* aux;        // EPI_BIAS_RELU_BN: optional post-ReLU store; EPI_DZ_INFER: post-ReLU activations (read)
+  const float* x0;   // EPI_SIGNSTEP
+  float* x_adv;
+  float alpha, eps;
+  float* part;             // *_STATS: [2][gridDim.y][N] per-row-tile column partial sums
+  const float* save_mean;  // EPI_DH_STATS: batch mean [N], rstd at +N
+  DropArgs drop;           // EPI_DH_STATS / EPI_DZ_NOBN
+  int ones_row;            // AMODE 1 only: row M-1 of op(A) is all ones (bias gradient = column sums of B)
+  float* extra_out;        // its output row goes here instead of C
+};
+
+// AMODE/BMODE 0: K contiguous in memory (operand(i,k) = P[i*ld + k]); 1: K strided (P[k*ld + i]).
+template <int MODE>
+__device__ __forceinline__ void load_frag(const float* __restrict__ P, int ld, int idx, int kb, int K, bool vec,
+                                          float (&f)[8], bool ones = false) {
+  if (MODE == 0) {
+    const float* p = P + (size_t)idx * ld + kb;
+    if (vec && kb + 8 <= K) {
+      const float4 lo = *reinterpret_cast<const float4*>(p);
+      const float4 hi = *reinterpret_cast<const float4*>(p + 4);
+      f[0] = lo.x; f[1] = lo.y; f[2] = lo.z; f[3] = lo.w;
+      f[4] = hi.x; f[5] = hi.y; f[6] = hi.z; f[7] = hi.w;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) f[q] = (kb + q < K) ? p[q] : 0.0f;
+    }
+  } else {
+    if (ones) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) f[q] = (kb + q < K) ? 1.0f : 0.0f;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) f[q] = (kb + q < K) ? P[(size_t)(kb + q) * ld + idx] : 0.0f;
+    }
+  }
+}
+
+// One output element: returns the value to store; s1/s2 receive the column statistics of the *_STATS epilogues.
+__device__ __forceinline__ float epilogue_elem(const GemmArgs& g, int step, int gm, int gn, float v, float& s1, float& s2) {
+  switch (g.epi) {
+    case EPI_BIAS:
+      return v + g.bias[gn];
+    case EPI_BIAS_RELU:
+      return fmaxf(v + g.bias[gn], 0.0f);
+    case EPI_BIAS_RELU_STATS: {
+      const float a = fmaxf(v + g.bias[gn], 0.0f);
+      s1 = a;
+      s2 = a * a;
+      return a;
+    }
+    case EPI_BIAS_RELU_BN: {
+      const float a = fmaxf(v + g.bias[gn], 0.0f);
+      if (g.aux) g.aux[(size_t)gm * g.ldc + gn] = a;
+      if (g.gamma) return (a - g.mmean[gn]) / sqrtf(g.mvar[gn] + kBnEps) * g.gamma[gn] + g.beta[gn];
+      return a;
+    }
+    case EPI_DZ_INFER: {
+      const float s = g.gamma ? g.gamma[gn] / sqrtf(g.mvar[gn] + kBnEps) : 1.0f;
+      return g.aux[(size_t)gm * g.ldc + gn] > 0.0f ? v * s : 0.0f;
+    }
+    case EPI_DH_STATS: {
+      const size_t e = (size_t)gm * g.ldc + gn;
+      const float gg = v * dropout_mult(g.drop, step, e);
+      const float xh = (g.aux[e] - g.save_mean[gn]) * g.save_mean[g.N + gn];
+      s1 = gg;
+      s2 = gg * xh;
+      return gg;
+    }
+    case EPI_DZ_NOBN: {
+      const size_t e = (size_t)gm * g.ldc + gn;
+      return g.aux[e] > 0.0f ? v * dropout_mult(g.drop, step, e) : 0.0f;
+    }
+    case EPI_SIGNSTEP: {
+      const size_t i = (size_t)gm * g.ldc + gn;
+      const float sg = (v > 0.0f) ? 1.0f : ((v < 0.0f) ? -1.0f : 0.0f);  // NaN -> 0, as ART zeroes NaN gradients
+      const float x0 = g.x0[i];
+      const float xa = g.x_adv[i] + g.alpha * sg;
+      if (isinf(g.eps)) return xa;
+      return x0 + fminf(fmaxf(xa - x0, -g.eps), g.eps);
+    }
+    default:
+      return v;
+  }
+}
+
+// T = 1: 32x32 output tile per workgroup; T = 2: 64x64 (each wavefront holds 2x2 accumulators, which halves
+// the L2 traffic per flop -- used when both output dimensions are large).  Either way the 4 wavefronts
+// split K and meet once in LDS.
+template <int AMODE, int BMODE, int T>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+  constexpr int TS = 32 * T;                   // tile side
+  constexpr int TPR = 8 * T;                   // threads per output row (one float4 each)
+  constexpr int RPP = 256 / TPR;               // rows per epilogue pass
+  constexpr int NPASS = TS / RPP;              // T*T
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [4][TS][TS] + stats [4][TPR][8]
+  float* stat = red + 4 * TS * TS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.y * TS, n0 = blockIdx.x * TS;
+  const int nch = (g.K + 15) >> 4;
+  const bool vecA = (AMODE == 0) && ((g.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0);
+  const bool vecB = (BMODE == 0) && ((g.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0);
+  const int m_real = g.ones_row ? g.M - 1 : g.M;  // rows of op(A) that exist in memory
+  int ai[T], bj[T];
+  bool aones[T];
+#pragma unroll
+  for (int i = 0; i < T; ++i) {
+    const int row = m0 + 32 * i + r;
+    aones[i] = (AMODE == 1) && g.ones_row && (row == g.M - 1);
+    ai[i] = min(row, m_real - 1);
+    bj[i] = min(n0 + 32 * i + r, g.N - 1);
+  }
+
+  f32x16 acc[T][T];
+#pragma unroll
+  for (int i = 0; i < T; ++i)
+#pragma unroll
+    for (int j = 0; j < T; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.0f;
+  float a0[T][8], b0[T][8], a1[T][8], b1[T][8];
+#pragma unroll
+  for (int i = 0; i < T; ++i)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { a0[i][q] = b0[i][q] = a1[i][q] = b1[i][q] = 0.0f; }
+
+  int c = wave;
+  if (c < nch) {
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+      load_frag<AMODE>(g.A, g.lda, ai[i], c * 16 + 8 * h, g.K, vecA, a0[i], aones[i]);
+      load_frag<BMODE>(g.B, g.ldb, bj[i], c * 16 + 8 * h, g.K, vecB, b0[i]);
+    }
+  }
+  while (c < nch) {
+    const int cn = c + 4;
+    if (cn < nch) {
+#pragma unroll
+      for (int i = 0; i < T; ++i) {
+        load_frag<AMODE>(g.A, g.lda, ai[i], cn * 16 + 8 * h, g.K, vecA, a1[i], aones[i]);
+        load_frag<BMODE>(g.B, g.ldb, bj[i], cn * 16 + 8 * h, g.K, vecB, b1[i]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+      for (int i = 0; i < T; ++i)
+#pragma unroll
+        for (int j = 0; j < T; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i][q], b0[j][q], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < T; ++i)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { a0[i][q] = a1[i][q]; b0[i][q] = b1[i][q]; }
+    c = cn;
+  }
+  // C/D map of one 32x32 accumulator: col = lane & 31, row = (q & 3) + 8 (q >> 2) + 4 (lane >> 5)
+#pragma unroll
+  for (int i = 0; i < T; ++i)
+#pragma unroll
+    for (int j = 0; j < T; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = 32 * i + (q & 3) + 8 * (q >> 2) + 4 * h;
+        red[wave * TS * TS + row * TS + 32 * j + r] = acc[i][j][q];
+      }
   __syncthreads();
-  part[ry][cx] = x;
+
+  const bool stats = (g.epi == EPI_BIAS_RELU_STATS) || (g.epi == EPI_DH_STATS);
+  const int step = g.drop.step_dev ? *g.drop.step_dev : 0;
+  const int tcol = tid % TPR, trow = tid / TPR;
+  const int c4 = tcol * 4;
+  const int gn = n0 + c4;
+  float cs1[4] = {0.f, 0.f, 0.f, 0.f}, cs2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int pass = 0; pass < NPASS; ++pass) {
+    const int row = trow + pass * RPP;
+    float4 s = *reinterpret_cast<const float4*>(red + row * TS + c4);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const float4 t = *reinterpret_cast<const float4*>(red + w * TS * TS + row * TS + c4);
+      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    const int gm = m0 + row;
+    if (gm < g.M) {
+      const float v[4] = {s.x, s.y, s.z, s.w};
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float t1 = 0.0f, t2 = 0.0f;
+        o[e] = (gn + e < g.N) ? epilogue_elem(g, step, gm, gn + e, v[e], t1, t2) : 0.0f;
+        cs1[e] += t1;
+        cs2[e] += t2;
+      }
+      float* crow;
+      if (g.ones_row && gm == g.M - 1) crow = g.extra_out;
+      else crow = (g.epi == EPI_SIGNSTEP ? g.x_adv : g.C) + (size_t)gm * g.ldc;
+      if (gn + 3 < g.N && ((g.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(crow) & 15) == 0)) {
+        *reinterpret_cast<float4*>(crow + gn) = make_float4(o[0], o[1], o[2], o[3]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (gn + e < g.N) crow[gn + e] = o[e];
+      }
+    }
+  }
+  if (stats) {
+    // reduce over the rows this wavefront touched (lanes with equal tcol), then over the 4 wavefronts
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+      for (int o = TPR; o < 64; o <<= 1) {
+        cs1[e] += __shfl_xor(cs1[e], o, 64);
+        cs2[e] += __shfl_xor(cs2[e], o, 64);
+      }
+    }
+    if (lane < TPR) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        stat[(wave * TPR + lane) * 8 + e] = cs1[e];
+        stat[(wave * TPR + lane) * 8 + 4 + e] = cs2[e];
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * TS) {
+      const int which = tid / TS, col = tid % TS;
+      const int l4 = col >> 2, e = col & 3;
+      float t = 0.0f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) t += stat[(w * TPR + l4) * 8 + which * 4 + e];
+      if (n0 + col < g.N) g.part[((size_t)which * gridDim.y + blockIdx.y) * g.N + n0 + col] = t;
+    }
+  }
+}
+
+template <int AMODE, int BMODE, int T>
+static void launch_gemm_t(const GemmArgs& g, hipStream_t st) {
+  constexpr int TS = 32 * T;
+  const dim3 grid((g.N + TS - 1) / TS, (g.M + TS - 1) / TS);
+  const size_t lds = (size_t)(4 * TS * TS + 4 * 8 * T * 8) * sizeof(float);
+  static bool attr_set = false;
+  if (lds > 48 * 1024 && !attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<AMODE, BMODE, T>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_f32_kernel<AMODE, BMODE, T>), grid, dim3(256), lds, st, g);
+}
+
+static int launch_gemm(int amode, int bmode, const GemmArgs& g, hipStream_t st) {
+  if (g.M <= 0 || g.N <= 0 || g.K <= 0) {
+    set_error("gemm: empty problem %dx%dx%d", g.M, g.N, g.K);
+    return LIPASR_EINVAL;
+  }
+  // The 64x64 variant (2x2 accumulators per wavefront) halves operand traffic but leaves one wavefront per
+  // SIMD and a quarter of the workgroups; measured on MI355X it is slower than 32x32 tiles at every layer of
+  // this classifier (profiles/r02_b), so it stays off.
+  const bool big = false;
+  if (big) {
+    if (amode == 0 && bmode == 0) launch_gemm_t<0, 0, 2>(g, st);
+    else if (amode == 0 && bmode == 1) launch_gemm_t<0, 1, 2>(g, st);
+    else if (amode == 1 && bmode == 0) launch_gemm_t<1, 0, 2>(g, st);
+    else launch_gemm_t<1, 1, 2>(g, st);
+  } else {
+    if (amode == 0 && bmode == 0) launch_gemm_t<0, 0, 1>(g, st);
+    else if (amode == 0 && bmode == 1) launch_gemm_t<0, 1, 1>(g, st);
+    else if (amode == 1 && bmode == 0) launch_gemm_t<1, 0, 1>(g, st);
+    else launch_gemm_t<1, 1, 1>(g, st);
+  }
+  LP_LAUNCH_CHECK();
+  return LIPASR_OK;
+}
+
+static int stats_row_tiles(int M, int N) { (void)N; return (M + 31) / 32; }
+
+static GemmArgs gemm_args(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
+                          int epi) {
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.epi = epi;
+  return g;
+}
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm / dropout apply kernels.  The column statistics arrive as per-row-tile partial sums from
+// the producing GEMM's epilogue, so these are plain 2-D elementwise kernels: grid = (column strips of
+// 128, row chunks of 32), 256 threads = 32 float4 column lanes x 8 row lanes, each workgroup re-sums
+// the (few) partials of its columns in fp64 in its prologue.  No cross-workgroup step, fixed order.
+// ---------------------------------------------------------------------------------------------
+constexpr int kApplyRows = 32;
+
+struct ColLane {
+  int j;      // first of this lane's 4 columns
+  bool vec;   // float4 access is legal
+  int N;
+};
+
+__device__ __forceinline__ void ld4(const float* __restrict__ p, size_t row_off, const ColLane& c, float (&v)[4]) {
+  if (c.vec) {
+    const float4 t = *reinterpret_cast<const float4*>(p + row_off + c.j);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (c.j + e < c.N) ? p[row_off + c.j + e] : 0.0f;
+  }
+}
+__device__ __forceinline__ void st4(float* __restrict__ p, size_t row_off, const ColLane& c, const float (&v)[4]) {
+  if (c.vec) {
+    *reinterpret_cast<float4*>(p + row_off + c.j) = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (c.j + e < c.N) p[row_off + c.j + e] = v[e];
+  }
+}
+
+// sums the two statistic planes of `part` over the row tiles for this lane's 4 columns (fp64, fixed order)
+__device__ __forceinline__ void sum_partials(const float* __restrict__ part, int n_tiles, const ColLane& c, int rl,
+                                             double (*lds)[32][8], int cl, double (&s1)[4], double (&s2)[4]) {
+  double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int t = rl; t < n_tiles; t += 8) {
+    float v1[4], v2[4];
+    ld4(part, (size_t)t * c.N, c, v1);
+    ld4(part, ((size_t)n_tiles + t) * c.N, c, v2);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { a[e] += (double)v1[e]; a[4 + e] += (double)v2[e]; }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) lds[rl][cl][e] = a[e];
   __syncthreads();
-  return ((part[0][cx] + part[1][cx]) + (part[2][cx] + part[3][cx])) +
-         ((part[4][cx] + part[5][cx]) + (part[6][cx] + part[7][cx]));
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { t1 += lds[k][cl][e]; t2 += lds[k][cl][4 + e]; }
+    s1[e] = t1;
+    s2[e] = t2;
+  }
 }
 
 struct BnFwdArgs {
   const float* a;  // [B][N] post-ReLU
   float* h;        // [B][N] out
-  int B, N, has_bn;
+  int B, N, has_bn, n_tiles;
+  const float* part;  // [2][n_tiles][N]: sums of a and a^2 per row tile
   const float* gamma;
   const float* beta;
   float* mmean;
@@ -221,119 +416,121 @@ struct BnFwdArgs {
   DropArgs drop;
 };
 
-// training-mode BatchNorm (batch statistics, population variance, two-pass) + inverted dropout.
-// One workgroup owns 32 columns and all B rows, so the statistics need no cross-workgroup step.
-__global__ __launch_bounds__(256) void bn_fwd_train_kernel(BnFwdArgs p) {
-  __shared__ float part[8][33];
-  const int tid = threadIdx.x, cx = tid & 31, ry = tid >> 5;
-  const int j = blockIdx.x * 32 + cx;
-  const bool live = j < p.N;
+// training-mode BatchNorm (batch mean, population variance) + inverted dropout
+__global__ __launch_bounds__(256) void bn_apply_fwd_kernel(BnFwdArgs p) {
+  __shared__ double lds[8][32][8];
+  const int tid = threadIdx.x, cl = tid & 31, rl = tid >> 5;
+  ColLane c;
+  c.j = blockIdx.x * 128 + 4 * cl;
+  c.N = p.N;
+  c.vec = ((p.N & 3) == 0) && (c.j + 3 < p.N);
+  const bool live = c.j < p.N;
   const int step = p.drop.step_dev ? *p.drop.step_dev : 0;
-  float mean = 0.0f, rstd = 1.0f, ga = 1.0f, be = 0.0f;
+  float mean[4] = {0, 0, 0, 0}, rstd[4] = {1, 1, 1, 1}, ga[4] = {1, 1, 1, 1}, be[4] = {0, 0, 0, 0};
   if (p.has_bn) {
-    float s = 0.0f;
-    if (live)
-      for (int b = ry; b < p.B; b += 8) s += p.a[(size_t)b * p.N + j];
-    mean = colblock_sum(s, part, cx, ry) / (float)p.B;
-    float q = 0.0f;
-    if (live)
-      for (int b = ry; b < p.B; b += 8) {
-        const float d = p.a[(size_t)b * p.N + j] - mean;
-        q = fmaf(d, d, q);
-      }
-    const float var = colblock_sum(q, part, cx, ry) / (float)p.B;
-    rstd = 1.0f / sqrtf(var + kBnEps);
+    double s1[4], s2[4];
+    ColLane cc = c;
+    if (!live) { cc.j = 0; cc.vec = false; cc.N = 0; }
+    sum_partials(p.part, p.n_tiles, cc, rl, lds, cl, s1, s2);
     if (live) {
-      ga = p.gamma[j];
-      be = p.beta[j];
-      if (ry == 0) {
-        p.save_mean[j] = mean;
-        p.save_mean[p.N + j] = rstd;
-        p.mmean[j] = p.mmean[j] * kBnMomentum + mean * (1.0f - kBnMomentum);
-        p.mvar[j] = p.mvar[j] * kBnMomentum + var * (1.0f - kBnMomentum);
+      float var[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const double m = s1[e] / (double)p.B;
+        double v = s2[e] / (double)p.B - m * m;
+        v = v > 0.0 ? v : 0.0;
+        mean[e] = (float)m;
+        var[e] = (float)v;
+        rstd[e] = (float)(1.0 / sqrt(v + (double)kBnEps));
+      }
+      ld4(p.gamma, 0, c, ga);
+      ld4(p.beta, 0, c, be);
+      if (blockIdx.y == 0 && rl == 0) {
+        float mm[4], mv[4];
+        ld4(p.mmean, 0, c, mm);
+        ld4(p.mvar, 0, c, mv);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          mm[e] = mm[e] * kBnMomentum + mean[e] * (1.0f - kBnMomentum);
+          mv[e] = mv[e] * kBnMomentum + var[e] * (1.0f - kBnMomentum);
+        }
+        st4(p.mmean, 0, c, mm);
+        st4(p.mvar, 0, c, mv);
+        st4(p.save_mean, 0, c, mean);
+        st4(p.save_mean, (size_t)p.N, c, rstd);
       }
     }
   }
   if (!live) return;
-  for (int b = ry; b < p.B; b += 8) {
-    const size_t e = (size_t)b * p.N + j;
-    float x = p.a[e];
-    if (p.has_bn) x = (x - mean) * rstd * ga + be;
-    p.h[e] = x * dropout_mult(p.drop, step, e);
+#pragma unroll
+  for (int i = 0; i < kApplyRows / 8; ++i) {
+    const int b = blockIdx.y * kApplyRows + rl + 8 * i;
+    if (b >= p.B) break;
+    const size_t ro = (size_t)b * p.N;
+    float x[4];
+    ld4(p.a, ro, c, x);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (p.has_bn) x[e] = (x[e] - mean[e]) * rstd[e] * ga[e] + be[e];
+      x[e] *= dropout_mult(p.drop, step, ro + c.j + e);
+    }
+    st4(p.h, ro, c, x);
   }
 }
 
 struct BnBwdArgs {
-  const float* dh;  // [B][N] gradient w.r.t. the layer's output (after BN and dropout)
+  const float* g;   // [B][N] dh * dropout (from the producing GEMM's epilogue)
   const float* a;   // [B][N] post-ReLU
   float* dz;        // [B][N] gradient w.r.t. the pre-activation
-  int B, N, has_bn;
+  int B, N, n_tiles;
+  const float* part;  // [2][n_tiles][N]: sums of g and g * xhat per row tile
   const float* gamma;
   const float* save_mean;
   float* dgamma;
   float* dbeta;
-  float* db;
-  DropArgs drop;
 };
 
-// backward of Dropout -> BatchNorm(train) -> ReLU in one kernel; also the bias gradient (column sum of dz)
-__global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs p) {
-  __shared__ float part[8][33];
-  const int tid = threadIdx.x, cx = tid & 31, ry = tid >> 5;
-  const int j = blockIdx.x * 32 + cx;
-  const bool live = j < p.N;
-  const int step = p.drop.step_dev ? *p.drop.step_dev : 0;
-  float mean = 0.0f, rstd = 1.0f, ga = 1.0f, dg = 0.0f, dbt = 0.0f;
-  if (p.has_bn) {
-    if (live) {
-      mean = p.save_mean[j];
-      rstd = p.save_mean[p.N + j];
-      ga = p.gamma[j];
-    }
-    float s1 = 0.0f, s2 = 0.0f;
-    if (live)
-      for (int b = ry; b < p.B; b += 8) {
-        const size_t e = (size_t)b * p.N + j;
-        const float g = p.dh[e] * dropout_mult(p.drop, step, e);
-        const float xh = (p.a[e] - mean) * rstd;
-        s1 = fmaf(g, xh, s1);
-        s2 += g;
-      }
-    dg = colblock_sum(s1, part, cx, ry);
-    dbt = colblock_sum(s2, part, cx, ry);
-    if (live && ry == 0) {
-      p.dgamma[j] = dg;
-      p.dbeta[j] = dbt;
-    }
+// backward of BatchNorm(train) -> ReLU given the column sums; also writes dgamma / dbeta
+__global__ __launch_bounds__(256) void bn_apply_bwd_kernel(BnBwdArgs p) {
+  __shared__ double lds[8][32][8];
+  const int tid = threadIdx.x, cl = tid & 31, rl = tid >> 5;
+  ColLane c;
+  c.j = blockIdx.x * 128 + 4 * cl;
+  c.N = p.N;
+  c.vec = ((p.N & 3) == 0) && (c.j + 3 < p.N);
+  const bool live = c.j < p.N;
+  double s1[4], s2[4];
+  ColLane cc = c;
+  if (!live) { cc.j = 0; cc.vec = false; cc.N = 0; }
+  sum_partials(p.part, p.n_tiles, cc, rl, lds, cl, s1, s2);
+  if (!live) return;
+  float mean[4], rstd[4], ga[4], dbt[4], dg[4];
+  ld4(p.save_mean, 0, c, mean);
+  ld4(p.save_mean, (size_t)p.N, c, rstd);
+  ld4(p.gamma, 0, c, ga);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { dbt[e] = (float)s1[e]; dg[e] = (float)s2[e]; }
+  if (blockIdx.y == 0 && rl == 0) {
+    st4(p.dbeta, 0, c, dbt);
+    st4(p.dgamma, 0, c, dg);
   }
   const float invB = 1.0f / (float)p.B;
-  float sb = 0.0f;
-  if (live)
-    for (int b = ry; b < p.B; b += 8) {
-      const size_t e = (size_t)b * p.N + j;
-      const float av = p.a[e];
-      float g = p.dh[e] * dropout_mult(p.drop, step, e);
-      if (p.has_bn) {
-        const float xh = (av - mean) * rstd;
-        g = ga * rstd * (g - dbt * invB - xh * dg * invB);
-      }
-      g = av > 0.0f ? g : 0.0f;
-      p.dz[e] = g;
-      sb += g;
+#pragma unroll
+  for (int i = 0; i < kApplyRows / 8; ++i) {
+    const int b = blockIdx.y * kApplyRows + rl + 8 * i;
+    if (b >= p.B) break;
+    const size_t ro = (size_t)b * p.N;
+    float gv[4], av[4], o[4];
+    ld4(p.g, ro, c, gv);
+    ld4(p.a, ro, c, av);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float xh = (av[e] - mean[e]) * rstd[e];
+      const float d = ga[e] * rstd[e] * (gv[e] - dbt[e] * invB - xh * dg[e] * invB);
+      o[e] = av[e] > 0.0f ? d : 0.0f;
     }
-  const float dbias = colblock_sum(sb, part, cx, ry);
-  if (live && ry == 0) p.db[j] = dbias;
-}
-
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int B, int N, float* __restrict__ out) {
-  __shared__ float part[8][33];
-  const int tid = threadIdx.x, cx = tid & 31, ry = tid >> 5;
-  const int j = blockIdx.x * 32 + cx;
-  float s = 0.0f;
-  if (j < N)
-    for (int b = ry; b < B; b += 8) s += x[(size_t)b * N + j];
-  const float t = colblock_sum(s, part, cx, ry);
-  if (j < N && ry == 0) out[j] = t;
+    st4(p.dz, ro, c, o);
+  }
 }
 
 // softmax + categorical cross-entropy from logits, one thread per row.
@@ -445,7 +642,8 @@ int lipasr_mlp_create(lipasr_handle_t h, int n_layers, const int* widths, const 
   m->offDzLast = wo; wo = align4(wo + (size_t)max_batch * C);
   m->offG0 = wo; wo = align4(wo + (size_t)max_batch * maxw);
   m->offG1 = wo; wo = align4(wo + (size_t)max_batch * maxw);
-  m->offLossTmp = wo; wo = align4(wo + (size_t)max_batch * C);
+  m->offG2 = wo; wo = align4(wo + (size_t)max_batch * maxw);
+  m->offPart = wo; wo = align4(wo + 2 * (size_t)((max_batch + 31) / 32) * maxw);  // column partials of the *_STATS epilogues
   m->ws_floats = wo;
   DeviceGuard g(h->device);
   if (hipMalloc(&m->ws, wo * sizeof(float)) != hipSuccess) {
@@ -595,29 +793,35 @@ int lipasr_mlp_train_fwd_bwd(lipasr_mlp_t m, const float* params, float* bnstate
   const int Lc = m->n_layers;
   const int C = m->L[Lc - 1].n_out;
   float* ws = m->ws;
+  float* part = ws + m->offPart;
+  const dim3 apply_block(256);
 
-  // ---- forward (training mode)
+  // ---- forward (training mode): GEMM (+bias, ReLU, column partials) -> BatchNorm/dropout apply
   const float* hin = x;
   for (int l = 0; l < Lc; ++l) {
     const MlpLayer& L = m->L[l];
     const bool last = (l == Lc - 1);
     float* outp = last ? (ws + m->offLogits) : (ws + L.offA);
     GemmArgs g = gemm_args(hin, L.n_in, params + L.offW, L.n_out, outp, L.n_out, batch, L.n_out, L.n_in,
-                           last ? EPI_BIAS : EPI_BIAS_RELU);
+                           last ? EPI_BIAS : (L.bn ? EPI_BIAS_RELU_STATS : EPI_BIAS_RELU));
     g.bias = params + L.offb;
+    g.part = part;
     rc = launch_gemm(0, 1, g, st);
     if (rc != LIPASR_OK) return rc;
     if (!last && L.offH != L.offA) {
       BnFwdArgs b;
       memset(&b, 0, sizeof(b));
       b.a = ws + L.offA; b.h = ws + L.offH; b.B = batch; b.N = L.n_out; b.has_bn = L.bn ? 1 : 0;
+      b.part = part;
+      b.n_tiles = stats_row_tiles(batch, L.n_out);
       if (L.bn) {
         b.gamma = params + L.offg; b.beta = params + L.offbe;
         b.mmean = bnstate + L.offmm; b.mvar = bnstate + L.offmv;
         b.save_mean = ws + L.offMean;
       }
       b.drop = drop_for_layer(m, l, dropout);
-      hipLaunchKernelGGL(bn_fwd_train_kernel, dim3((L.n_out + 31) / 32), dim3(256), 0, st, b);
+      const dim3 grid((L.n_out + 127) / 128, (batch + kApplyRows - 1) / kApplyRows);
+      hipLaunchKernelGGL(bn_apply_fwd_kernel, grid, apply_block, 0, st, b);
       LP_LAUNCH_CHECK();
       hin = ws + L.offH;
     } else {
@@ -630,41 +834,49 @@ int lipasr_mlp_train_fwd_bwd(lipasr_mlp_t m, const float* params, float* bnstate
                      (float*)nullptr);
   LP_LAUNCH_CHECK();
 
-  // ---- backward
-  const float* gin = ws + m->offDzLast;  // gradient at layer l's pre-activation
+  // ---- backward.  gin = gradient at layer l's pre-activation.  Three rotating buffers: the dX GEMM reads
+  // gin and writes the next buffer, the BatchNorm-backward apply writes the one after.
+  float* G[3] = {ws + m->offG0, ws + m->offG1, ws + m->offG2};
+  const float* gin = ws + m->offDzLast;
+  int cur = 2;  // so that the first dX output lands in G[0]
   for (int l = Lc - 1; l >= 0; --l) {
     const MlpLayer& L = m->L[l];
-    const bool last = (l == Lc - 1);
-    if (last) {
-      hipLaunchKernelGGL(colsum_kernel, dim3((L.n_out + 31) / 32), dim3(256), 0, st, gin, batch, L.n_out,
-                         grads + L.offb);
-      LP_LAUNCH_CHECK();
-    } else {
-      BnBwdArgs b;
-      memset(&b, 0, sizeof(b));
-      b.dh = ws + m->offG0; b.a = ws + L.offA; b.dz = ws + m->offG1; b.B = batch; b.N = L.n_out;
-      b.has_bn = L.bn ? 1 : 0;
-      if (L.bn) {
-        b.gamma = params + L.offg; b.save_mean = ws + L.offMean;
-        b.dgamma = grads + L.offg; b.dbeta = grads + L.offbe;
-      }
-      b.db = grads + L.offb;
-      b.drop = drop_for_layer(m, l, dropout);
-      hipLaunchKernelGGL(bn_bwd_kernel, dim3((L.n_out + 31) / 32), dim3(256), 0, st, b);
-      LP_LAUNCH_CHECK();
-      gin = ws + m->offG1;
-    }
     const float* lin = (l == 0) ? x : (ws + m->L[l - 1].offH);
-    // dW[n_in][n_out] = lin^T[n_in][B] * gin[B][n_out]   (both operands K(=batch)-strided)
-    GemmArgs gw = gemm_args(lin, L.n_in, gin, L.n_out, grads + L.offW, L.n_out, L.n_in, L.n_out, batch, EPI_STORE);
+    // [dW ; db] = [lin ; 1]^T[n_in+1][B] * gin[B][n_out]: the all-ones row yields the bias gradient
+    GemmArgs gw = gemm_args(lin, L.n_in, gin, L.n_out, grads + L.offW, L.n_out, L.n_in + 1, L.n_out, batch, EPI_STORE);
+    gw.ones_row = 1;
+    gw.extra_out = grads + L.offb;
     rc = launch_gemm(1, 1, gw, st);
     if (rc != LIPASR_OK) return rc;
-    if (l > 0) {
-      // dh_prev[B][n_in] = gin[B][n_out] * W^T
-      GemmArgs gx = gemm_args(gin, L.n_out, params + L.offW, L.n_out, ws + m->offG0, L.n_in, batch, L.n_in, L.n_out,
-                              EPI_STORE);
-      rc = launch_gemm(0, 0, gx, st);
-      if (rc != LIPASR_OK) return rc;
+    if (l == 0) break;
+    const MlpLayer& P = m->L[l - 1];
+    // dh_prev[B][n_in] = gin[B][n_out] * W^T, fused with the backward of Dropout (and the BN column sums)
+    float* out1 = G[(cur + 1) % 3];
+    GemmArgs gx = gemm_args(gin, L.n_out, params + L.offW, L.n_out, out1, L.n_in, batch, L.n_in, L.n_out,
+                            P.bn ? EPI_DH_STATS : EPI_DZ_NOBN);
+    gx.aux = ws + P.offA;
+    gx.drop = drop_for_layer(m, l - 1, dropout);
+    gx.part = part;
+    if (P.bn) gx.save_mean = ws + P.offMean;
+    rc = launch_gemm(0, 0, gx, st);
+    if (rc != LIPASR_OK) return rc;
+    if (P.bn) {
+      float* out2 = G[(cur + 2) % 3];
+      BnBwdArgs b;
+      memset(&b, 0, sizeof(b));
+      b.g = out1; b.a = ws + P.offA; b.dz = out2; b.B = batch; b.N = P.n_out;
+      b.part = part;
+      b.n_tiles = stats_row_tiles(batch, P.n_out);
+      b.gamma = params + P.offg; b.save_mean = ws + P.offMean;
+      b.dgamma = grads + P.offg; b.dbeta = grads + P.offbe;
+      const dim3 grid((P.n_out + 127) / 128, (batch + kApplyRows - 1) / kApplyRows);
+      hipLaunchKernelGGL(bn_apply_bwd_kernel, grid, apply_block, 0, st, b);
+      LP_LAUNCH_CHECK();
+      gin = out2;
+      cur = (cur + 2) % 3;
+    } else {
+      gin = out1;
+      cur = (cur + 1) % 3;
     }
   }
   return LIPASR_OK;

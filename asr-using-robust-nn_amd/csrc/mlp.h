@@ -32,5 +32,5 @@ struct lipasr_mlp {
   size_t n_params = 0, n_state = 0;
   float* ws = nullptr;  // workspace
   size_t ws_floats = 0;
-  size_t offLogits = 0, offProb = 0, offDzLast = 0, offG0 = 0, offG1 = 0, offLossTmp = 0;
+  size_t offLogits = 0, offProb = 0, offDzLast = 0, offG0 = 0, offG1 = 0, offG2 = 0, offPart = 0;
 };
