@@ -28,12 +28,20 @@ struct MfccPlan {
   bool identity = false;  // sr_in == 22050
   float* d_h = nullptr;   // [up][taps]
   int* d_noff = nullptr;  // [up]
+  float* d_hband = nullptr;  // [n_ptiles][kRsBand][32]: banded taps of 32-phase tiles (MFMA resampler)
+  int* d_lo = nullptr;       // [n_ptiles]: n_off of each tile's first phase
+  int n_ptiles = 0;
+  int stage_mask = 0;        // debug/profiling: bit0 skip FFT passes, bit1 skip mel, bit2 use the VALU resampler
   float* d_hann = nullptr;
   float* d_tw = nullptr;  // float2 [2048]
   int* d_mel_start = nullptr;
   int* d_mel_len = nullptr;
   int* d_mel_off = nullptr;
   float* d_mel_w = nullptr;
+  float* d_mel_wlo = nullptr;  // [1025] two-filters-per-bin form (mel_pairs)
+  float* d_mel_whi = nullptr;
+  int* d_mel_pstart = nullptr;  // [128]
+  int* d_mel_plen = nullptr;
   float* d_dct = nullptr;  // [20][128]
   float* d_y = nullptr;    // [batch_max][n_y]
   float* d_db = nullptr;   // [batch_max][n_frames][128]
@@ -45,7 +53,7 @@ struct MfccPlan {
 
 void mfcc_plan_free(MfccPlan* p) {
   if (!p) return;
-  void* ptrs[] = {p->d_h, p->d_noff, p->d_hann, p->d_tw, p->d_mel_start, p->d_mel_len, p->d_mel_off,
+  void* ptrs[] = {p->d_mel_wlo, p->d_mel_whi, p->d_mel_pstart, p->d_mel_plen, p->d_hband, p->d_lo, p->d_h, p->d_noff, p->d_hann, p->d_tw, p->d_mel_start, p->d_mel_len, p->d_mel_off,
                   p->d_mel_w, p->d_dct, p->d_y, p->d_db, p->d_fmax};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
@@ -127,6 +135,84 @@ __global__ __launch_bounds__(256) void resample_generic_kernel(const float* __re
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// stage 1, MFMA form (16 kHz / 8 kHz -> 22.05 kHz: up = 441, 128 taps).
+//   For a tile of 32 consecutive phases p0..p0+31 every tap reads an input sample in a band of at most
+//   152 consecutive samples (offsets n_p0 .. n_p0+151 from the block start - 63), so
+//       Y[utterance i][phase j] = sum_kk  X[i][kk] * Hband[kk][j]
+//   is a 32 x 32 x 152 GEMM per (32 utterances, q-block, phase tile) on v_mfma_f32_32x32x2_f32 (exact
+//   fp32 fma chain; the zero taps of the band add exact zeros).  One workgroup = 32 utterances x 1
+//   q-block: the 32 x 448 input samples sit in LDS (row stride 481 = 1 mod 32: the A-operand read
+//   `lane i -> row i` is conflict-free; 61.6 kB, so two workgroups share a CU and one's float4 fill
+//   overlaps the other's MFMAs), 7 wavefronts take 2 of the 14 phase tiles each, the 76 tap fragments
+//   of a tile are loaded up front (coalesced 128 B per half-wave from the L2-resident 272 kB table).
+//   Output rows are phases: 128 B contiguous stores per half-wave.
+// ---------------------------------------------------------------------------------------------
+constexpr int kRsBand = 152, kRsStride = 481, kRsWaves = 7;
+typedef float rs_f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(64 * kRsWaves) void resample_mfma_kernel(const float* __restrict__ x, int n_samp, int batch,
+                                                                       float* __restrict__ y, int n_valid, int n_y,
+                                                                       int up, int down, int left, int n_ptiles,
+                                                                       const float* __restrict__ Hband,
+                                                                       const int* __restrict__ lo, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];  // [32][kRsStride]; xs[i][t] = x_i[down*q - 64 + t]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, h = lane >> 5;
+  const int u0 = blockIdx.y * 32, q = blockIdx.x;
+  const int base = down * q - left;  // = down*q - 64: one sample before the first tap, 16-byte aligned
+  constexpr int kVecPerRow = (kRsStride - 1) / 4;  // 120 float4 = 480 floats per row
+  const bool vec = ((n_samp & 3) == 0) && ((down & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  if (!(dbg & 16)) {
+    if (vec) {
+      for (int f = tid; f < 32 * kVecPerRow; f += 64 * kRsWaves) {
+        const int i = f / kVecPerRow, v = f - i * kVecPerRow;
+        const int u = u0 + i, n = base + 4 * v;
+        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (u < batch && n >= 0 && n + 3 < n_samp) val = *reinterpret_cast<const float4*>(x + (size_t)u * n_samp + n);
+        float* d = xs + i * kRsStride + 4 * v;
+        d[0] = val.x; d[1] = val.y; d[2] = val.z; d[3] = val.w;
+      }
+      if (tid < 32) xs[tid * kRsStride + kRsStride - 1] = 0.0f;
+    } else {
+      for (int f = tid; f < 32 * kRsStride; f += 64 * kRsWaves) {
+        const int i = f / kRsStride, t = f - i * kRsStride;
+        const int u = u0 + i, n = base + t;
+        xs[f] = (u < batch && n >= 0 && n < n_samp) ? x[(size_t)u * n_samp + n] : 0.0f;
+      }
+    }
+  }
+  __syncthreads();
+  for (int r = wave; r < n_ptiles; r += kRsWaves) {
+    rs_f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+    const float* hb = Hband + (size_t)r * kRsBand * 32 + h * 32 + li;
+    const float* xa = xs + li * kRsStride + lo[r] + 1 + h;
+    // all 76 tap fragments of this phase tile go to registers first: 76 coalesced loads in flight at once
+    float bq[kRsBand / 2];
+#pragma unroll
+    for (int s = 0; s < kRsBand / 2; ++s) bq[s] = hb[s * 64];
+    __builtin_amdgcn_sched_barrier(0);  // keep every load ahead of the MFMA chain (do not sink them back in)
+    if (dbg & 8) {
+      acc[0] = bq[0] + bq[75] + xa[0];
+    } else {
+#pragma unroll
+      for (int s = 0; s < kRsBand / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[2 * s], bq[s], acc, 0, 0, 0);
+    }
+    const int p = 32 * r + li;
+    const int t = q * up + p;
+    if (p < up && t < n_y) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int u = u0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (u < batch) y[(size_t)u * n_y + t] = t < n_valid ? acc[e] : 0.0f;
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void copy_pad_kernel(const float* __restrict__ x, int n_samp, float* __restrict__ y,
                                                         int n_y) {
   const int u = blockIdx.y;
@@ -137,11 +223,15 @@ __global__ __launch_bounds__(256) void copy_pad_kernel(const float* __restrict__
 // ---------------------------------------------------------------------------------------------
 // stage 2: STFT -> power -> mel -> dB
 // ---------------------------------------------------------------------------------------------
-constexpr int kFftLds = 2048 + 64;
-__device__ __forceinline__ int padi(int i) { return i + (i >> 5); }
+// LDS holds complex points as float2; element e lives at e + e/8.  With that padding the 16-lane groups of
+// ds_write_b64 / ds_read_b64 hit 16 distinct 8-byte slots in the radix-8 scatter of passes 1 and 2
+// (strides 8 and 64 elements) and at most a 2-way overlap in the unit-stride passes.
+constexpr int kFftLds = 2048 + 2048 / 8;
+__device__ __forceinline__ int padi(int i) { return i + (i >> 3); }
 
 // np.pad(y, 1024, mode='reflect') index: position j relative to y[0], any j, n >= 2
 __device__ __forceinline__ int reflect_index(int j, int n) {
+  if ((unsigned)j < (unsigned)n) return j;  // interior frames never reflect
   const int period = 2 * (n - 1);
   int m = j % period;
   if (m < 0) m += period;
@@ -179,35 +269,40 @@ __device__ __forceinline__ void butterfly(cpx (&v)[8]) { dft8(v); }
 __device__ __forceinline__ void butterfly(cpx (&v)[4]) { dft4(v); }
 
 // one Stockham pass of radix R over 2048 points: butterfly j reads src[j + r*2048/R], multiplies by
-// exp(-2 pi i r k/(Ns R)) with k = j mod Ns, writes dst[(j/Ns) Ns R + k + r Ns]
+// w^r, w = exp(-2 pi i k/(Ns R)), k = j mod Ns, writes dst[(j/Ns) Ns R + k + r Ns].
+// Twiddles: w, w^2, w^4 come from the table, the other powers are one complex product away.
 template <int R>
-__device__ __forceinline__ void fft_pass(const float* __restrict__ sre, const float* __restrict__ sim,
-                                         float* __restrict__ dre, float* __restrict__ dim, int Ns, int j,
+__device__ __forceinline__ void fft_pass(const float2* __restrict__ src, float2* __restrict__ dst, int Ns, int j,
                                          const float2* __restrict__ tw) {
   constexpr int NR = 2048 / R;
   cpx v[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    const int i = padi(j + r * NR);
-    v[r] = {sre[i], sim[i]};
+    const float2 t = src[padi(j + r * NR)];
+    v[r] = {t.x, t.y};
   }
   const int k = j & (Ns - 1);
   if (Ns > 1) {
     const int tstep = k * (2048 / (Ns * R));
-#pragma unroll
-    for (int r = 1; r < R; ++r) {
-      const float2 w = tw[(r * tstep) & 2047];
-      v[r] = cmul(v[r], cpx{w.x, w.y});
+    const float2 t1 = tw[tstep & 2047], t2 = tw[(2 * tstep) & 2047];
+    const cpx w1 = {t1.x, t1.y}, w2 = {t2.x, t2.y};
+    const cpx w3 = cmul(w1, w2);
+    v[1] = cmul(v[1], w1);
+    v[2] = cmul(v[2], w2);
+    v[3] = cmul(v[3], w3);
+    if (R == 8) {
+      const float2 t4 = tw[(4 * tstep) & 2047];
+      const cpx w4 = {t4.x, t4.y};
+      v[4 % R] = cmul(v[4 % R], w4);
+      v[5 % R] = cmul(v[5 % R], cmul(w1, w4));
+      v[6 % R] = cmul(v[6 % R], cmul(w2, w4));
+      v[7 % R] = cmul(v[7 % R], cmul(w3, w4));
     }
   }
   butterfly(v);
   const int j0 = (j - k) * R + k;
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int i = padi(j0 + r * Ns);
-    dre[i] = v[r].re;
-    dim[i] = v[r].im;
-  }
+  for (int r = 0; r < R; ++r) dst[padi(j0 + r * Ns)] = make_float2(v[r].re, v[r].im);
 }
 
 struct StftArgs {
@@ -215,16 +310,20 @@ struct StftArgs {
   int n_y, n_frames;
   const float* hann;
   const float2* tw;
-  const int* mel_start;
+  const float* mel_wlo;  // [1025]
+  const float* mel_whi;  // [1025]
+  const int* mel_start;  // [128] run of bins whose lower filter is m
   const int* mel_len;
-  const int* mel_off;
-  const float* mel_w;
   float* db;    // [B][n_frames][128]
   float* fmax;  // [B][n_frames]
+  int stage_mask;  // profiling only: bit0 skip the FFT passes, bit1 skip the mel reduction (results are wrong)
 };
 
+constexpr int kTStride = 1028;  // per-array stride of the four weighted-power arrays (>= 1025)
+
 __global__ __launch_bounds__(256) void stft_mel_kernel(StftArgs a) {
-  __shared__ float bufA_re[kFftLds], bufA_im[kFftLds], bufB_re[kFftLds], bufB_im[kFftLds];
+  __shared__ __attribute__((aligned(16))) float2 bufA[kFftLds];
+  __shared__ __attribute__((aligned(16))) float2 bufB[kFftLds];
   __shared__ float wmax[4];
   const int tid = threadIdx.x;
   const int u = blockIdx.y;
@@ -239,38 +338,53 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(StftArgs a) {
     const int j0 = f0 * 512 + n - 1024;
     const float s0 = yu[reflect_index(j0, a.n_y)];
     const float s1 = has1 ? yu[reflect_index(j0 + 512, a.n_y)] : 0.0f;
-    const int i = padi(n);
-    bufA_re[i] = w * s0;
-    bufA_im[i] = w * s1;
+    bufA[padi(n)] = make_float2(w * s0, w * s1);
   }
   __syncthreads();
-  fft_pass<8>(bufA_re, bufA_im, bufB_re, bufB_im, 1, tid, a.tw);
-  __syncthreads();
-  fft_pass<8>(bufB_re, bufB_im, bufA_re, bufA_im, 8, tid, a.tw);
-  __syncthreads();
-  fft_pass<8>(bufA_re, bufA_im, bufB_re, bufB_im, 64, tid, a.tw);
-  __syncthreads();
-  fft_pass<4>(bufB_re, bufB_im, bufA_re, bufA_im, 512, tid, a.tw);
-  fft_pass<4>(bufB_re, bufB_im, bufA_re, bufA_im, 512, tid + 256, a.tw);
-  __syncthreads();
+  if (!(a.stage_mask & 1)) {
+    fft_pass<8>(bufA, bufB, 1, tid, a.tw);
+    __syncthreads();
+    fft_pass<8>(bufB, bufA, 8, tid, a.tw);
+    __syncthreads();
+    fft_pass<8>(bufA, bufB, 64, tid, a.tw);
+    __syncthreads();
+    fft_pass<4>(bufB, bufA, 512, tid, a.tw);
+    fft_pass<4>(bufB, bufA, 512, tid + 256, a.tw);
+    __syncthreads();
+  }
   // Z = FFT(frame0 + i frame1) in bufA.  X0[k] = (Z[k] + conj Z[N-k])/2, X1[k] = (Z[k] - conj Z[N-k])/(2i).
-  // power spectra into bufB_re (frame 0) and bufB_im (frame 1), bins 0..1024 (unpadded indices)
+  // The power of bin k is multiplied straight away by its two mel weights: T[2 sel + 0][k] = wlo[k] P_sel[k],
+  // T[2 sel + 1][k] = whi[k] P_sel[k]  (four float arrays laid over bufB).
+  float* T = reinterpret_cast<float*>(bufB);
   for (int k = tid; k <= 1024; k += 256) {
-    const int i = padi(k), i2 = padi((2048 - k) & 2047);
-    const float zr = bufA_re[i], zi = bufA_im[i];
-    const float wr = bufA_re[i2], wi = -bufA_im[i2];
+    const float2 z = bufA[padi(k)], zc = bufA[padi((2048 - k) & 2047)];
+    const float zr = z.x, zi = z.y, wr = zc.x, wi = -zc.y;
     const float x0r = 0.5f * (zr + wr), x0i = 0.5f * (zi + wi);
     const float x1r = 0.5f * (zi - wi), x1i = -0.5f * (zr - wr);
-    bufB_re[k] = x0r * x0r + x0i * x0i;
-    bufB_im[k] = x1r * x1r + x1i * x1i;
+    const float p0 = x0r * x0r + x0i * x0i, p1 = x1r * x1r + x1i * x1i;
+    const float wl = a.mel_wlo[k], wh = a.mel_whi[k];
+    T[k] = wl * p0;
+    T[kTStride + k] = wh * p0;
+    T[2 * kTStride + k] = wl * p1;
+    T[3 * kTStride + k] = wh * p1;
   }
   __syncthreads();
   const int sel = tid >> 7, m = tid & 127;
-  const float* P = sel ? bufB_im : bufB_re;
-  const int st = a.mel_start[m], ln = a.mel_len[m];
-  const float* w = a.mel_w + a.mel_off[m];
+  const float* T1 = T + 2 * sel * kTStride;
+  const float* T2 = T1 + kTStride;
   float s = 0.0f;
-  for (int i = 0; i < ln; ++i) s = fmaf(w[i], P[st + i], s);
+  if (!(a.stage_mask & 2)) {
+    const int st = a.mel_start[m], ln = a.mel_len[m];
+    for (int i = 0; i < ln; ++i) s += T1[st + i];
+    if (m > 0) {
+      const int st2 = a.mel_start[m - 1], ln2 = a.mel_len[m - 1];
+      float s2 = 0.0f;
+      for (int i = 0; i < ln2; ++i) s2 += T2[st2 + i];
+      s += s2;
+    }
+  } else {
+    s = T1[m];
+  }
   const float dbv = 10.0f * log10f(fmaxf(1e-10f, s));  // librosa.power_to_db(ref=1, amin=1e-10)
   const int f = sel ? f1 : f0;
   const bool valid = f < a.n_frames;
@@ -368,6 +482,31 @@ __global__ __launch_bounds__(256) void add_noise_kernel(float* __restrict__ y, i
   }
 }
 
+// Banded taps [n_tiles][kRsBand][32] and first-phase offsets [n_tiles] for the MFMA resampler; false when the
+// ratio does not fit its fixed geometry (128 taps, band <= 152 samples, LDS row of 801 floats).
+static bool build_band_tables(const Polyphase& pp, std::vector<float>* hb_out, std::vector<int>* lo_out) {
+  if (!(pp.taps == 128 && pp.left == 64 && pp.down + 128 <= kRsStride - 1)) return false;
+  const int nt = (pp.up + 31) / 32;
+  std::vector<float> hb((size_t)nt * kRsBand * 32, 0.0f);
+  std::vector<int> lo(nt, 0);
+  for (int r = 0; r < nt; ++r) {
+    const int p0 = 32 * r;
+    lo[r] = pp.n_off[p0];
+    for (int j = 0; j < 32; ++j) {
+      const int ph = p0 + j;
+      if (ph >= pp.up) break;
+      const int d = pp.n_off[ph] - pp.n_off[p0];
+      if (d < 0 || d + 128 > kRsBand) return false;
+      for (int t = 0; t < 128; ++t) hb[((size_t)r * kRsBand + d + t) * 32 + j] = pp.h[(size_t)ph * 128 + t];
+    }
+    // the last sample a workgroup's band can touch must stay inside its LDS row
+    if (lo[r] + 1 + kRsBand > kRsStride) return false;
+  }
+  *hb_out = hb;
+  *lo_out = lo;
+  return true;
+}
+
 template <typename T>
 static int upload(T** dptr, const std::vector<T>& v) {
   LP_HIP(hipMalloc(dptr, v.size() * sizeof(T)));
@@ -382,7 +521,17 @@ static int launch_resample(const MfccPlan* p, const float* wav, int batch, float
     return LIPASR_OK;
   }
   const int nq = (p->n_y + p->up - 1) / p->up;
-  if (p->taps == 128 && p->up <= 448) {
+  if (p->d_hband && !(p->stage_mask & 4)) {
+    const size_t lds = (size_t)32 * kRsStride * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+      LP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(resample_mfma_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(resample_mfma_kernel, dim3(nq, (batch + 31) / 32), dim3(64 * kRsWaves), lds, st, wav,
+                       p->n_samp, batch, y, p->n_valid, p->n_y, p->up, p->down, p->left, p->n_ptiles, p->d_hband, p->d_lo, p->stage_mask);
+  } else if (p->taps == 128 && p->up <= 448) {
     const int nb = (nq + kRsQBlocks - 1) / kRsQBlocks;
     const size_t lds = (size_t)(kRsQBlocks * p->down + 128) * sizeof(float);
     hipLaunchKernelGGL(resample_reg128_kernel, dim3(nb, batch), dim3(448), lds, st, wav, p->n_samp, y, p->n_valid,
@@ -401,8 +550,9 @@ static int launch_from_22k(const MfccPlan* p, const float* y, int batch, int L, 
   StftArgs a;
   a.y = y; a.n_y = p->n_y; a.n_frames = p->n_frames; a.hann = p->d_hann;
   a.tw = reinterpret_cast<const float2*>(p->d_tw);
-  a.mel_start = p->d_mel_start; a.mel_len = p->d_mel_len; a.mel_off = p->d_mel_off; a.mel_w = p->d_mel_w;
+  a.mel_wlo = p->d_mel_wlo; a.mel_whi = p->d_mel_whi; a.mel_start = p->d_mel_pstart; a.mel_len = p->d_mel_plen;
   a.db = p->d_db; a.fmax = p->d_fmax;
+  a.stage_mask = p->stage_mask;
   hipLaunchKernelGGL(stft_mel_kernel, dim3((p->n_frames + 1) / 2, batch), dim3(256), 0, st, a);
   LP_LAUNCH_CHECK();
   if (mid) LP_HIP(hipEventRecord(mid, st));
@@ -452,8 +602,30 @@ int lipasr_mfcc_plan(lipasr_handle_t h, int sr_in, int n_samp, int batch_max) {
       mfcc_plan_free(p);
       return rc;
     }
+    {
+      std::vector<float> hb;
+      std::vector<int> lo;
+      if (build_band_tables(pp, &hb, &lo)) {
+        p->n_ptiles = (int)lo.size();
+        if ((rc = upload(&p->d_hband, hb)) != LIPASR_OK || (rc = upload(&p->d_lo, lo)) != LIPASR_OK) {
+          mfcc_plan_free(p);
+          return rc;
+        }
+      }
+    }
   }
   MelSparse ms = mel_sparse();
+  MelPairs mp = mel_pairs();
+  if (!mp.ok) {
+    mfcc_plan_free(p);
+    set_error("lipasr_mfcc_plan: mel filter bank is not a two-filters-per-bin bank");
+    return LIPASR_EUNSUPPORTED;
+  }
+  if ((rc = upload(&p->d_mel_wlo, mp.wlo)) != LIPASR_OK || (rc = upload(&p->d_mel_whi, mp.whi)) != LIPASR_OK ||
+      (rc = upload(&p->d_mel_pstart, mp.start)) != LIPASR_OK || (rc = upload(&p->d_mel_plen, mp.len)) != LIPASR_OK) {
+    mfcc_plan_free(p);
+    return rc;
+  }
   if ((rc = upload(&p->d_hann, hann_periodic())) != LIPASR_OK || (rc = upload(&p->d_tw, twiddles())) != LIPASR_OK ||
       (rc = upload(&p->d_mel_start, ms.start)) != LIPASR_OK || (rc = upload(&p->d_mel_len, ms.len)) != LIPASR_OK ||
       (rc = upload(&p->d_mel_off, ms.off)) != LIPASR_OK || (rc = upload(&p->d_mel_w, ms.w)) != LIPASR_OK ||
@@ -572,6 +744,16 @@ int lipasr_add_noise_f32(lipasr_handle_t h, float* y, int batch, int n, int mode
   return LIPASR_OK;
 }
 
+/* Profiling knob: key 0 = MFCC stage mask (bit0 skip FFT passes, bit1 skip mel reduction, bit2 use the VALU
+ * resampler instead of the MFMA one).  Masks 1 and 2 give wrong results by design. */
+int lipasr_debug_set(lipasr_handle_t h, int key, int value) {
+  LP_CHECK_ARG(h != nullptr, "lipasr_debug_set: null handle");
+  LP_CHECK_ARG(key == 0, "lipasr_debug_set: unknown key %d", key);
+  if (!h->mfcc) { set_error("lipasr_debug_set: call lipasr_mfcc_plan first"); return LIPASR_ESTATE; }
+  h->mfcc->stage_mask = value;
+  return LIPASR_OK;
+}
+
 /* Host-only: copies one constant table (as the kernels see it) into `out`; returns the element count
  * (or a negative error).  which: 0 hann[2048], 1 dct[20*128], 2 dense mel[128*1025], 3 polyphase taps
  * [up*taps] for sr_in, 4 polyphase meta {up, down, taps, left} as floats, 5 phase offsets as floats. */
@@ -581,12 +763,31 @@ int lipasr_debug_table(int which, int sr_in, float* out, int cap) {
     case 0: v = hann_periodic(); break;
     case 1: v = dct_matrix(); break;
     case 2: v = mel_dense(); break;
-    case 3: case 4: case 5: {
+    case 3: case 4: case 5: case 6: case 7: {
       LP_CHECK_ARG(sr_in >= 1000 && sr_in != kSr, "lipasr_debug_table: sr_in=%d", sr_in);
       Polyphase pp = build_polyphase(sr_in, kSr);
       if (which == 3) v = pp.h;
       else if (which == 4) v = {(float)pp.up, (float)pp.down, (float)pp.taps, (float)pp.left};
-      else v.assign(pp.n_off.begin(), pp.n_off.end());
+      else if (which == 5) v.assign(pp.n_off.begin(), pp.n_off.end());
+      else {
+        std::vector<float> hb;
+        std::vector<int> lo;
+        if (!build_band_tables(pp, &hb, &lo)) { set_error("lipasr_debug_table: no banded form for sr_in=%d", sr_in); return LIPASR_EUNSUPPORTED; }
+        if (which == 6) v = hb;
+        else v.assign(lo.begin(), lo.end());
+      }
+      break;
+    }
+    case 8: {  // the mel bank as the kernel applies it (pair form), expanded to dense [128*1025]
+      MelPairs mp = mel_pairs();
+      LP_CHECK_ARG(mp.ok, "lipasr_debug_table: mel bank has no pair form");
+      v.assign((size_t)kNMels * kNBins, 0.0f);
+      for (int m = 0; m < kNMels; ++m)
+        for (int i = 0; i < mp.len[m]; ++i) {
+          const int b = mp.start[m] + i;
+          v[(size_t)m * kNBins + b] += mp.wlo[b];
+          if (m + 1 < kNMels) v[(size_t)(m + 1) * kNBins + b] += mp.whi[b];
+        }
       break;
     }
     default: set_error("lipasr_debug_table: unknown table %d", which); return LIPASR_EINVAL;

@@ -184,6 +184,45 @@ inline MelSparse mel_sparse() {
   return s;
 }
 
+// Two-filters-per-bin form of the same bank: bin k feeds filter lo[k] with weight wlo[k] and filter lo[k]+1
+// with weight whi[k]; lo is non-decreasing, so the bins of filter m form the run [start[m], start[m]+len[m]):
+//   mel[m] = sum_{k in run(m)} wlo[k] P[k] + sum_{k in run(m-1)} whi[k] P[k].
+// ok = false if the bank does not have that structure (then the CSR form is used).
+struct MelPairs {
+  std::vector<float> wlo, whi;  // [1025]
+  std::vector<int> start, len;  // [128]
+  bool ok = true;
+};
+inline MelPairs mel_pairs() {
+  MelPairs mp;
+  std::vector<float> W = mel_dense();
+  mp.wlo.assign(kNBins, 0.0f); mp.whi.assign(kNBins, 0.0f);
+  mp.start.assign(kNMels, 0); mp.len.assign(kNMels, 0);
+  std::vector<int> lo(kNBins, 0);
+  int prev = 0;
+  for (int b = 0; b < kNBins; ++b) {
+    int first = -1, count = 0;
+    for (int m = 0; m < kNMels; ++m)
+      if (W[(size_t)m * kNBins + b] != 0.0f) { if (first < 0) first = m; ++count; }
+    if (count == 0) { lo[b] = prev; continue; }
+    if (count > 2 || first < prev) { mp.ok = false; return mp; }
+    if (count == 2 && W[(size_t)(first + 1) * kNBins + b] == 0.0f) { mp.ok = false; return mp; }
+    lo[b] = first;
+    mp.wlo[b] = W[(size_t)first * kNBins + b];
+    if (count == 2) mp.whi[b] = W[(size_t)(first + 1) * kNBins + b];
+    prev = first;
+  }
+  for (int m = 0; m < kNMels; ++m) { mp.start[m] = kNBins; }
+  for (int b = 0; b < kNBins; ++b) {
+    const int m = lo[b];
+    if (mp.len[m] == 0) mp.start[m] = b;
+    mp.len[m]++;
+  }
+  for (int m = 0; m < kNMels; ++m)
+    if (mp.len[m] == 0) mp.start[m] = 0;
+  return mp;
+}
+
 // rows 0..19 of scipy.fftpack.dct(type=2, norm='ortho') over 128 points, float32 [20][128]
 inline std::vector<float> dct_matrix() {
   std::vector<float> D((size_t)kNMfcc * kNMels);

@@ -262,6 +262,10 @@ int lipasr_mfcc_profile_end(lipasr_handle_t h, float* avg_ms3, int* n_calls);
 int lipasr_add_noise_f32(lipasr_handle_t h, float* y, int batch, int n, int mode, float p0, float p1,
                          uint64_t seed, lipasr_stream_t stream);
 
+/* Profiling knob.  key 0: MFCC stage mask (bit0 skip the FFT passes, bit1 skip the mel reduction -- both give
+ * wrong results and exist to time the remaining stages; bit2 selects the VALU resampler instead of the MFMA one). */
+int lipasr_debug_set(lipasr_handle_t h, int key, int value);
+
 /* Host-only (no GPU needed): copies one constant table, exactly as the kernels read it, into `out`
  * and returns its element count (negative = error); out may be NULL to query the size.
  * which: 0 Hann[2048]; 1 DCT[20*128]; 2 dense mel filter bank[128*1025]; 3 polyphase resampling taps

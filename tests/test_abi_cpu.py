@@ -45,6 +45,33 @@ def test_tables_equal_oracle():
     np.testing.assert_array_equal(N.debug_table(0), M.hann_periodic().astype(np.float32))
     np.testing.assert_allclose(N.debug_table(1).reshape(20, 128), M.dct_matrix(), atol=1e-7)
     np.testing.assert_array_equal(N.debug_table(2).reshape(128, 1025), M.mel_filterbank())
+    # the two-filters-per-bin form the STFT kernel applies expands to the same dense bank, bit for bit
+    np.testing.assert_array_equal(N.debug_table(8).reshape(128, 1025), M.mel_filterbank())
+
+
+def test_banded_resampler_tables():
+    """The MFMA resampler's banded taps reproduce the oracle (NumPy emulation of the kernel's index math)."""
+    for sr in (16000, 8000):
+        up, down, taps, left = (int(v) for v in N.debug_table(4, sr))
+        hb = N.debug_table(6, sr).reshape(-1, 152, 32).astype(np.float64)
+        lo = N.debug_table(7, sr).astype(int)
+        x = np.random.default_rng(sr).standard_normal(sr // 2).astype(np.float32)
+        ref = M.resample_kaiser_best(x, sr, 22050)
+        nq = (len(ref) + up - 1) // up
+        y = np.zeros(nq * up + 64)
+        for q0 in range(0, nq, 2):
+            xs = np.zeros(801)
+            for t in range(2 * down + 127):
+                n = down * q0 - (left - 1) + t
+                if 0 <= n < len(x):
+                    xs[t] = x[n]
+            for r in range(len(lo)):
+                for ql in range(2):
+                    if q0 + ql < nq:
+                        out = xs[lo[r] + ql * down: lo[r] + ql * down + 152] @ hb[r]
+                        n_ph = min(32, up - 32 * r)
+                        y[(q0 + ql) * up + 32 * r: (q0 + ql) * up + 32 * r + n_ph] = out[:n_ph]
+        np.testing.assert_allclose(y[:len(ref)], ref, atol=2e-6)
 
 
 @pytest.mark.parametrize("sr_in,n", [(16000, 3000), (8000, 1500), (44100, 6000), (48000, 6000)])
