@@ -149,17 +149,14 @@ __device__ __forceinline__ float epilogue_elem(const GemmArgs& g, int step, int 
   }
 }
 
-// T = 1: 32x32 output tile per workgroup; T = 2: 64x64 (each wavefront holds 2x2 accumulators, which halves
-// the L2 traffic per flop -- used when both output dimensions are large).  Either way the 4 wavefronts
-// split K and meet once in LDS.
-template <int AMODE, int BMODE, int T>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
-  constexpr int TS = 32 * T;                   // tile side
-  constexpr int TPR = 8 * T;                   // threads per output row (one float4 each)
-  constexpr int RPP = 256 / TPR;               // rows per epilogue pass
-  constexpr int NPASS = TS / RPP;              // T*T
-  extern __shared__ __attribute__((aligned(16))) float red[];  // [4][TS][TS] + stats [4][TPR][8]
-  float* stat = red + 4 * TS * TS;
+// One workgroup = one 32x32 output tile; its NW wavefronts (4, or 16 for small outputs with a long K) split K
+// in 16-deep chunks, round-robin.  Operand fragments go global/L2 -> VGPR directly, one chunk ahead of the MFMAs.
+template <int AMODE, int BMODE, int NW>
+__global__ __launch_bounds__(64 * NW) void gemm_f32_kernel(GemmArgs g) {
+  constexpr int TS = 32;
+  constexpr int TPR = 8;                       // threads per output row (one float4 each)
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [NW][32][32] + stats [4][8][8]
+  float* stat = red + NW * TS * TS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int m0 = blockIdx.y * TS, n0 = blockIdx.x * TS;
@@ -167,82 +164,53 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   const bool vecA = (AMODE == 0) && ((g.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0);
   const bool vecB = (BMODE == 0) && ((g.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0);
   const int m_real = g.ones_row ? g.M - 1 : g.M;  // rows of op(A) that exist in memory
-  int ai[T], bj[T];
-  bool aones[T];
-#pragma unroll
-  for (int i = 0; i < T; ++i) {
-    const int row = m0 + 32 * i + r;
-    aones[i] = (AMODE == 1) && g.ones_row && (row == g.M - 1);
-    ai[i] = min(row, m_real - 1);
-    bj[i] = min(n0 + 32 * i + r, g.N - 1);
-  }
+  const int row_a = m0 + r;
+  const bool aones = (AMODE == 1) && g.ones_row && (row_a == g.M - 1);
+  const int ai = min(row_a, m_real - 1);
+  const int bj = min(n0 + r, g.N - 1);
 
-  f32x16 acc[T][T];
+  f32x16 acc;
 #pragma unroll
-  for (int i = 0; i < T; ++i)
+  for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+  float a0[8], b0[8], a1[8], b1[8];
 #pragma unroll
-    for (int j = 0; j < T; ++j)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.0f;
-  float a0[T][8], b0[T][8], a1[T][8], b1[T][8];
-#pragma unroll
-  for (int i = 0; i < T; ++i)
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { a0[i][q] = b0[i][q] = a1[i][q] = b1[i][q] = 0.0f; }
-
+  for (int q = 0; q < 8; ++q) { a0[q] = b0[q] = a1[q] = b1[q] = 0.0f; }
+  // one chunk of loads in flight behind the MFMAs
   int c = wave;
   if (c < nch) {
-#pragma unroll
-    for (int i = 0; i < T; ++i) {
-      load_frag<AMODE>(g.A, g.lda, ai[i], c * 16 + 8 * h, g.K, vecA, a0[i], aones[i]);
-      load_frag<BMODE>(g.B, g.ldb, bj[i], c * 16 + 8 * h, g.K, vecB, b0[i]);
-    }
+    load_frag<AMODE>(g.A, g.lda, ai, c * 16 + 8 * h, g.K, vecA, a0, aones);
+    load_frag<BMODE>(g.B, g.ldb, bj, c * 16 + 8 * h, g.K, vecB, b0);
   }
   while (c < nch) {
-    const int cn = c + 4;
+    const int cn = c + NW;
     if (cn < nch) {
-#pragma unroll
-      for (int i = 0; i < T; ++i) {
-        load_frag<AMODE>(g.A, g.lda, ai[i], cn * 16 + 8 * h, g.K, vecA, a1[i], aones[i]);
-        load_frag<BMODE>(g.B, g.ldb, bj[i], cn * 16 + 8 * h, g.K, vecB, b1[i]);
-      }
+      load_frag<AMODE>(g.A, g.lda, ai, cn * 16 + 8 * h, g.K, vecA, a1, aones);
+      load_frag<BMODE>(g.B, g.ldb, bj, cn * 16 + 8 * h, g.K, vecB, b1);
     }
 #pragma unroll
-    for (int q = 0; q < 8; ++q)
+    for (int q = 0; q < 8; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q], b0[q], acc, 0, 0, 0);
 #pragma unroll
-      for (int i = 0; i < T; ++i)
-#pragma unroll
-        for (int j = 0; j < T; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i][q], b0[j][q], acc[i][j], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < T; ++i)
-#pragma unroll
-      for (int q = 0; q < 8; ++q) { a0[i][q] = a1[i][q]; b0[i][q] = b1[i][q]; }
+    for (int q = 0; q < 8; ++q) { a0[q] = a1[q]; b0[q] = b1[q]; }
     c = cn;
   }
   // C/D map of one 32x32 accumulator: col = lane & 31, row = (q & 3) + 8 (q >> 2) + 4 (lane >> 5)
 #pragma unroll
-  for (int i = 0; i < T; ++i)
-#pragma unroll
-    for (int j = 0; j < T; ++j)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int row = 32 * i + (q & 3) + 8 * (q >> 2) + 4 * h;
-        red[wave * TS * TS + row * TS + 32 * j + r] = acc[i][j][q];
-      }
+  for (int q = 0; q < 16; ++q) {
+    const int row = (q & 3) + 8 * (q >> 2) + 4 * h;
+    red[wave * TS * TS + row * TS + r] = acc[q];
+  }
   __syncthreads();
 
   const bool stats = (g.epi == EPI_BIAS_RELU_STATS) || (g.epi == EPI_DH_STATS);
-  const int step = g.drop.step_dev ? *g.drop.step_dev : 0;
-  const int tcol = tid % TPR, trow = tid / TPR;
-  const int c4 = tcol * 4;
-  const int gn = n0 + c4;
   float cs1[4] = {0.f, 0.f, 0.f, 0.f}, cs2[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int pass = 0; pass < NPASS; ++pass) {
-    const int row = trow + pass * RPP;
+  if (tid < 256) {
+    const int step = g.drop.step_dev ? *g.drop.step_dev : 0;
+    const int tcol = tid & 7, row = tid >> 3;
+    const int c4 = tcol * 4;
+    const int gn = n0 + c4;
     float4 s = *reinterpret_cast<const float4*>(red + row * TS + c4);
 #pragma unroll
-    for (int w = 1; w < 4; ++w) {
+    for (int w = 1; w < NW; ++w) {
       const float4 t = *reinterpret_cast<const float4*>(red + w * TS * TS + row * TS + c4);
       s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
     }
@@ -254,8 +222,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
       for (int e = 0; e < 4; ++e) {
         float t1 = 0.0f, t2 = 0.0f;
         o[e] = (gn + e < g.N) ? epilogue_elem(g, step, gm, gn + e, v[e], t1, t2) : 0.0f;
-        cs1[e] += t1;
-        cs2[e] += t2;
+        cs1[e] = t1;
+        cs2[e] = t2;
       }
       float* crow;
       if (g.ones_row && gm == g.M - 1) crow = g.extra_out;
@@ -270,20 +238,22 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     }
   }
   if (stats) {
-    // reduce over the rows this wavefront touched (lanes with equal tcol), then over the 4 wavefronts
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-#pragma unroll
-      for (int o = TPR; o < 64; o <<= 1) {
-        cs1[e] += __shfl_xor(cs1[e], o, 64);
-        cs2[e] += __shfl_xor(cs2[e], o, 64);
-      }
-    }
-    if (lane < TPR) {
+    // column sums over the tile's 32 rows: lanes with equal tcol inside a wavefront (8 rows), then 4 wavefronts
+    if (tid < 256) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        stat[(wave * TPR + lane) * 8 + e] = cs1[e];
-        stat[(wave * TPR + lane) * 8 + 4 + e] = cs2[e];
+#pragma unroll
+        for (int o = TPR; o < 64; o <<= 1) {
+          cs1[e] += __shfl_xor(cs1[e], o, 64);
+          cs2[e] += __shfl_xor(cs2[e], o, 64);
+        }
+      }
+      if (lane < TPR) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          stat[(wave * TPR + lane) * 8 + e] = cs1[e];
+          stat[(wave * TPR + lane) * 8 + 4 + e] = cs2[e];
+        }
       }
     }
     __syncthreads();
@@ -298,18 +268,17 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   }
 }
 
-template <int AMODE, int BMODE, int T>
+template <int AMODE, int BMODE, int NW>
 static void launch_gemm_t(const GemmArgs& g, hipStream_t st) {
-  constexpr int TS = 32 * T;
-  const dim3 grid((g.N + TS - 1) / TS, (g.M + TS - 1) / TS);
-  const size_t lds = (size_t)(4 * TS * TS + 4 * 8 * T * 8) * sizeof(float);
+  const dim3 grid((g.N + 31) / 32, (g.M + 31) / 32);
+  const size_t lds = (size_t)(NW * 32 * 32 + 4 * 8 * 8) * sizeof(float);
   static bool attr_set = false;
   if (lds > 48 * 1024 && !attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<AMODE, BMODE, T>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<AMODE, BMODE, NW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_f32_kernel<AMODE, BMODE, T>), grid, dim3(256), lds, st, g);
+  hipLaunchKernelGGL((gemm_f32_kernel<AMODE, BMODE, NW>), grid, dim3(64 * NW), lds, st, g);
 }
 
 static int launch_gemm(int amode, int bmode, const GemmArgs& g, hipStream_t st) {
@@ -317,20 +286,20 @@ static int launch_gemm(int amode, int bmode, const GemmArgs& g, hipStream_t st) 
     set_error("gemm: empty problem %dx%dx%d", g.M, g.N, g.K);
     return LIPASR_EINVAL;
   }
-  // The 64x64 variant (2x2 accumulators per wavefront) halves operand traffic but leaves one wavefront per
-  // SIMD and a quarter of the workgroups; measured on MI355X it is slower than 32x32 tiles at every layer of
-  // this classifier (profiles/r02_b), so it stays off.
-  const bool big = false;
-  if (big) {
-    if (amode == 0 && bmode == 0) launch_gemm_t<0, 0, 2>(g, st);
-    else if (amode == 0 && bmode == 1) launch_gemm_t<0, 1, 2>(g, st);
-    else if (amode == 1 && bmode == 0) launch_gemm_t<1, 0, 2>(g, st);
-    else launch_gemm_t<1, 1, 2>(g, st);
+  // Few output tiles and a long K (the dW GEMMs of the narrow layers, K = batch): 16 wavefronts split K so that
+  // the serial chain of chunk loads per wavefront stays short.  Not for the *_STATS epilogues (never needed there).
+  const long tiles = (long)((g.N + 31) / 32) * ((g.M + 31) / 32);
+  const bool deep = tiles <= 192 && g.K >= 512 && g.epi != EPI_BIAS_RELU_STATS && g.epi != EPI_DH_STATS;
+  if (deep) {
+    if (amode == 0 && bmode == 0) launch_gemm_t<0, 0, 16>(g, st);
+    else if (amode == 0 && bmode == 1) launch_gemm_t<0, 1, 16>(g, st);
+    else if (amode == 1 && bmode == 0) launch_gemm_t<1, 0, 16>(g, st);
+    else launch_gemm_t<1, 1, 16>(g, st);
   } else {
-    if (amode == 0 && bmode == 0) launch_gemm_t<0, 0, 1>(g, st);
-    else if (amode == 0 && bmode == 1) launch_gemm_t<0, 1, 1>(g, st);
-    else if (amode == 1 && bmode == 0) launch_gemm_t<1, 0, 1>(g, st);
-    else launch_gemm_t<1, 1, 1>(g, st);
+    if (amode == 0 && bmode == 0) launch_gemm_t<0, 0, 4>(g, st);
+    else if (amode == 0 && bmode == 1) launch_gemm_t<0, 1, 4>(g, st);
+    else if (amode == 1 && bmode == 0) launch_gemm_t<1, 0, 4>(g, st);
+    else launch_gemm_t<1, 1, 4>(g, st);
   }
   LP_LAUNCH_CHECK();
   return LIPASR_OK;

@@ -46,7 +46,15 @@ __global__ __launch_bounds__(256) void chain_step_kernel(const float* __restrict
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int total = R * n_in;
   if (p_mode == 0) {
-    for (int f = tid; f < total; f += 256) Ps[f] = Pin[f];
+    if ((total & 3) == 0 && (reinterpret_cast<uintptr_t>(Pin) & 15) == 0) {
+      const float4* src = reinterpret_cast<const float4*>(Pin);
+      float4* dst = reinterpret_cast<float4*>(Ps);
+      const int t4 = total >> 2;
+#pragma unroll 4
+      for (int f = tid; f < t4; f += 256) dst[f] = src[f];
+    } else {
+      for (int f = tid; f < total; f += 256) Ps[f] = Pin[f];
+    }
   } else if (p_mode == 1) {
     for (int f = tid; f < total; f += 256) {
       int j = f / R, r = f - j * R;
@@ -148,13 +156,27 @@ __global__ __launch_bounds__(256) void product_sigma_kernel(const double* __rest
                                                              float* __restrict__ norms_out, float* __restrict__ sigma_out) {
   __shared__ double A[kMaxR * kMaxR];
   __shared__ double B[kMaxR * kMaxR];
+  __shared__ double slice_sum[4 * kMaxR * kMaxR];
   __shared__ double tr_s;
   const int tid = threadIdx.x;
   const int RR = R * R;
-  for (int e = tid; e < RR; e += 256) {
-    double s = 0.0;
-    for (int p = 0; p < n_part; ++p) s += gram_part[(size_t)p * RR + e];
-    A[e] = s;
+  // Gram = sum of the per-workgroup partials: entries over threads, partial index split 4 ways (fixed order)
+  {
+    for (int e = tid; e < RR * 4; e += 256) {
+      const int ent = e % RR, sl = e / RR;
+      const int p0 = (n_part * sl) / 4, p1 = (n_part * (sl + 1)) / 4;
+      double s0 = 0.0, s1 = 0.0;
+      int p = p0;
+      for (; p + 1 < p1; p += 2) {
+        s0 += gram_part[(size_t)p * RR + ent];
+        s1 += gram_part[(size_t)(p + 1) * RR + ent];
+      }
+      if (p < p1) s0 += gram_part[(size_t)p * RR + ent];
+      slice_sum[sl * kMaxR * kMaxR + ent] = s0 + s1;
+    }
+    __syncthreads();
+    for (int e = tid; e < RR; e += 256)
+      A[e] = (slice_sum[e] + slice_sum[kMaxR * kMaxR + e]) + (slice_sum[2 * kMaxR * kMaxR + e] + slice_sum[3 * kMaxR * kMaxR + e]);
   }
   __syncthreads();
   if (tid == 0) {

@@ -1,4 +1,4 @@
-import sys, ctypes as C; sys.path.insert(0,'.'); sys.path.insert(0,'asr-using-robust-nn_amd')
+import sys, ctypes as C; import os; R=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0,R); sys.path.insert(0,os.path.join(R,'asr-using-robust-nn_amd'))
 import numpy as np, torch
 import lipasr._native as N
 from lipasr.extract_features_construct_dataset import MfccExtractor
@@ -9,7 +9,7 @@ wt=torch.as_tensor(w).cuda()
 ex=MfccExtractor(16000,16000,B)
 out=torch.empty(B,880,device='cuda')
 s=torch.cuda.Stream()
-for mask in (0,8,16,24):
+for mask in (0,32,1,2):
     N.check(N.lib.lipasr_debug_set(ex.h.h,0,mask))
     with torch.cuda.stream(s):
         for _ in range(3): ex(wt,44,out=out)
