@@ -621,6 +621,15 @@ int lipasr_mlp_create(lipasr_handle_t h, int n_layers, const int* widths, const 
     return LIPASR_ENOMEM;
   }
   (void)hipMemset(m->ws, 0, wo * sizeof(float));
+  bool ok = hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) == hipSuccess;
+  for (int l = 0; l < n_layers && ok; ++l)
+    ok = hipEventCreateWithFlags(&m->ev_fork[l], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&m->ev_dw[l], hipEventDisableTiming) == hipSuccess;
+  if (!ok) {
+    (void)lipasr_mlp_destroy(m);
+    set_error("lipasr_mlp_create: side stream / event creation failed");
+    return LIPASR_EHIP;
+  }
   *out = m;
   return LIPASR_OK;
 }
@@ -629,6 +638,11 @@ int lipasr_mlp_destroy(lipasr_mlp_t m) {
   LP_CHECK_ARG(m != nullptr, "lipasr_mlp_destroy: null plan");
   DeviceGuard g(m->ctx->device);
   if (m->ws) (void)hipFree(m->ws);
+  for (int l = 0; l < LIPASR_MAX_LAYERS; ++l) {
+    if (m->ev_fork[l]) (void)hipEventDestroy(m->ev_fork[l]);
+    if (m->ev_dw[l]) (void)hipEventDestroy(m->ev_dw[l]);
+  }
+  if (m->side) (void)hipStreamDestroy(m->side);
   delete m;
   return LIPASR_OK;
 }
@@ -811,13 +825,19 @@ int lipasr_mlp_train_fwd_bwd(lipasr_mlp_t m, const float* params, float* bnstate
   for (int l = Lc - 1; l >= 0; --l) {
     const MlpLayer& L = m->L[l];
     const float* lin = (l == 0) ? x : (ws + m->L[l - 1].offH);
-    // [dW ; db] = [lin ; 1]^T[n_in+1][B] * gin[B][n_out]: the all-ones row yields the bias gradient
+    // [dW ; db] = [lin ; 1]^T[n_in+1][B] * gin[B][n_out]: the all-ones row yields the bias gradient.
+    // Forked onto the side stream: it only feeds the optimizer, the dX chain below does not wait for it.
     GemmArgs gw = gemm_args(lin, L.n_in, gin, L.n_out, grads + L.offW, L.n_out, L.n_in + 1, L.n_out, batch, EPI_STORE);
     gw.ones_row = 1;
     gw.extra_out = grads + L.offb;
-    rc = launch_gemm(1, 1, gw, st);
+    LP_HIP(hipEventRecord(m->ev_fork[l], st));
+    LP_HIP(hipStreamWaitEvent(m->side, m->ev_fork[l], 0));
+    rc = launch_gemm(1, 1, gw, m->side);
     if (rc != LIPASR_OK) return rc;
+    LP_HIP(hipEventRecord(m->ev_dw[l], m->side));
     if (l == 0) break;
+    // the dX GEMM below overwrites the buffer that held layer l+1's gin, which dW(l+1) may still be reading
+    if (l + 1 < Lc) LP_HIP(hipStreamWaitEvent(st, m->ev_dw[l + 1], 0));
     const MlpLayer& P = m->L[l - 1];
     // dh_prev[B][n_in] = gin[B][n_out] * W^T, fused with the backward of Dropout (and the BN column sums)
     float* out1 = G[(cur + 1) % 3];
@@ -848,6 +868,9 @@ int lipasr_mlp_train_fwd_bwd(lipasr_mlp_t m, const float* params, float* bnstate
       cur = (cur + 1) % 3;
     }
   }
+  // join: every weight gradient is complete before anything later on `stream` (the side stream runs its GEMMs
+  // in order, so the last event covers them all)
+  LP_HIP(hipStreamWaitEvent(st, m->ev_dw[0], 0));
   return LIPASR_OK;
 }
 

@@ -224,11 +224,12 @@ __global__ __launch_bounds__(256) void copy_pad_kernel(const float* __restrict__
 // ---------------------------------------------------------------------------------------------
 // stage 2: STFT -> power -> mel -> dB
 // ---------------------------------------------------------------------------------------------
-// LDS holds complex points as float2; element e lives at e + e/8.  With that padding the 16-lane groups of
-// ds_write_b64 / ds_read_b64 hit 16 distinct 8-byte slots in the radix-8 scatter of passes 1 and 2
-// (strides 8 and 64 elements) and at most a 2-way overlap in the unit-stride passes.
-constexpr int kFftLds = 2048 + 2048 / 8;
-__device__ __forceinline__ int padi(int i) { return i + (i >> 3); }
+// LDS holds complex points as float2; element e lives at e ^ ((e >> 4) & 7) (no padding).  Unit-stride
+// accesses (every read, the writes of passes 3 and 4) stay a permutation inside aligned 8-element blocks, i.e.
+// conflict-free for ds_read_b64's 32-lane halves, and the stride-8 scatter of pass 1 lands its 16-lane write
+// groups on 16 distinct 8-byte slots (pass 2's stride-64 scatter is 2-way).
+constexpr int kFftLds = 2048 + 72;  // + room for the four weighted-power arrays laid over one buffer
+__device__ __forceinline__ int padi(int i) { return i ^ ((i >> 4) & 7); }
 
 // np.pad(y, 1024, mode='reflect') index: position j relative to y[0], any j, n >= 2
 __device__ __forceinline__ int reflect_index(int j, int n) {
@@ -272,16 +273,30 @@ __device__ __forceinline__ void butterfly(cpx (&v)[4]) { dft4(v); }
 // one Stockham pass of radix R over 2048 points: butterfly j reads src[j + r*2048/R], multiplies by
 // w^r, w = exp(-2 pi i k/(Ns R)), k = j mod Ns, writes dst[(j/Ns) Ns R + k + r Ns].
 // Twiddles: w, w^2, w^4 come from the table, the other powers are one complex product away.
-template <int R>
-__device__ __forceinline__ void fft_pass(const float2* __restrict__ src, float2* __restrict__ dst, int Ns, int j,
-                                         const float2* __restrict__ tw) {
+// In place on one LDS buffer: every thread reads its inputs, the workgroup meets (sync_between), then writes.
+template <int R, int NB>
+__device__ __forceinline__ void fft_pass(float2* __restrict__ buf, int Ns, int j0_, const float2* __restrict__ tw,
+                                         const cpx* __restrict__ regs = nullptr) {
   constexpr int NR = 2048 / R;
-  cpx v[R];
+  cpx vv[NB][R];
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const float2 t = src[padi(j + r * NR)];
-    v[r] = {t.x, t.y};
+  for (int b = 0; b < NB; ++b) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (regs) {
+        vv[b][r] = regs[r];  // pass 1: butterfly j's inputs x[j + r*256] are exactly what thread j loaded
+      } else {
+        const float2 t = buf[padi(j0_ + 256 * b + r * NR)];
+        vv[b][r] = {t.x, t.y};
+      }
+    }
   }
+  if (!regs) __syncthreads();  // all reads of this pass are done before anybody overwrites the buffer
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    cpx (&v)[R] = vv[b];
+    const int j = j0_ + 256 * b;
+    float2* dst = buf;
   const int k = j & (Ns - 1);
   if (Ns > 1) {
     const int tstep = k * (2048 / (Ns * R));
@@ -304,6 +319,7 @@ __device__ __forceinline__ void fft_pass(const float2* __restrict__ src, float2*
   const int j0 = (j - k) * R + k;
 #pragma unroll
   for (int r = 0; r < R; ++r) dst[padi(j0 + r * Ns)] = make_float2(v[r].re, v[r].im);
+  }
 }
 
 struct StftArgs {
@@ -323,8 +339,7 @@ struct StftArgs {
 constexpr int kTStride = 1060;  // per-array stride of the four weighted-power arrays (padded index k + k/32 <= 1056)
 
 __global__ __launch_bounds__(256) void stft_mel_kernel(StftArgs a) {
-  __shared__ __attribute__((aligned(16))) float2 bufA[kFftLds];
-  __shared__ __attribute__((aligned(16))) float2 bufB[kFftLds];
+  __shared__ __attribute__((aligned(16))) float2 buf[kFftLds];  // ONE buffer: 17 kB per workgroup
   __shared__ float wmax[4];
   const int tid = threadIdx.x;
   const int u = blockIdx.y;
@@ -332,6 +347,7 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(StftArgs a) {
   const bool has1 = f1 < a.n_frames;
   const float* yu = a.y + (size_t)u * a.n_y;
   // frame f covers padded positions [512 f, 512 f + 2048) = y positions [512 f - 1024, ...)
+  cpx x0[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int n = tid + 256 * e;
@@ -339,36 +355,51 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(StftArgs a) {
     const int j0 = f0 * 512 + n - 1024;
     const float s0 = yu[reflect_index(j0, a.n_y)];
     const float s1 = has1 ? yu[reflect_index(j0 + 512, a.n_y)] : 0.0f;
-    bufA[padi(n)] = make_float2(w * s0, w * s1);
+    x0[e] = {w * s0, w * s1};
+  }
+  if (a.stage_mask & 1) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) buf[padi(tid + 256 * e)] = make_float2(x0[e].re, x0[e].im);
+    __syncthreads();
+  } else {
+    fft_pass<8, 1>(buf, 1, tid, a.tw, x0);  // straight from registers: no staging write
+    __syncthreads();
+    fft_pass<8, 1>(buf, 8, tid, a.tw);
+    __syncthreads();
+    fft_pass<8, 1>(buf, 64, tid, a.tw);
+    __syncthreads();
+    fft_pass<4, 2>(buf, 512, tid, a.tw);  // radix 4: two butterflies per thread
+    __syncthreads();
+  }
+  // Z = FFT(frame0 + i frame1).  X0[k] = (Z[k] + conj Z[N-k])/2, X1[k] = (Z[k] - conj Z[N-k])/(2i).
+  // The power of bin k is multiplied straight away by its two mel weights: T[2 sel + 0][k] = wlo[k] P_sel[k],
+  // T[2 sel + 1][k] = whi[k] P_sel[k]  (four float arrays laid over the same buffer once Z has been read).
+  float2 zz[5], zc[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int k = tid + 256 * i;
+    if (k <= 1024) {
+      zz[i] = buf[padi(k)];
+      zc[i] = buf[padi((2048 - k) & 2047)];
+    }
   }
   __syncthreads();
-  if (!(a.stage_mask & 1)) {
-    fft_pass<8>(bufA, bufB, 1, tid, a.tw);
-    __syncthreads();
-    fft_pass<8>(bufB, bufA, 8, tid, a.tw);
-    __syncthreads();
-    fft_pass<8>(bufA, bufB, 64, tid, a.tw);
-    __syncthreads();
-    fft_pass<4>(bufB, bufA, 512, tid, a.tw);
-    fft_pass<4>(bufB, bufA, 512, tid + 256, a.tw);
-    __syncthreads();
-  }
-  // Z = FFT(frame0 + i frame1) in bufA.  X0[k] = (Z[k] + conj Z[N-k])/2, X1[k] = (Z[k] - conj Z[N-k])/(2i).
-  // The power of bin k is multiplied straight away by its two mel weights: T[2 sel + 0][k] = wlo[k] P_sel[k],
-  // T[2 sel + 1][k] = whi[k] P_sel[k]  (four float arrays laid over bufB).
-  float* T = reinterpret_cast<float*>(bufB);
-  for (int k = tid; k <= 1024; k += 256) {
-    const float2 z = bufA[padi(k)], zc = bufA[padi((2048 - k) & 2047)];
-    const float zr = z.x, zi = z.y, wr = zc.x, wi = -zc.y;
-    const float x0r = 0.5f * (zr + wr), x0i = 0.5f * (zi + wi);
-    const float x1r = 0.5f * (zi - wi), x1i = -0.5f * (zr - wr);
-    const float p0 = x0r * x0r + x0i * x0i, p1 = x1r * x1r + x1i * x1i;
-    const float wl = a.mel_wlo[k], wh = a.mel_whi[k];
-    const int pk = k + (k >> 5);  // runs of neighbouring mels start ~32 bins apart at the top of the band
-    T[pk] = wl * p0;
-    T[kTStride + pk] = wh * p0;
-    T[2 * kTStride + pk] = wl * p1;
-    T[3 * kTStride + pk] = wh * p1;
+  float* T = reinterpret_cast<float*>(buf);
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int k = tid + 256 * i;
+    if (k <= 1024) {
+      const float zr = zz[i].x, zi = zz[i].y, wr = zc[i].x, wi = -zc[i].y;
+      const float x0r = 0.5f * (zr + wr), x0i = 0.5f * (zi + wi);
+      const float x1r = 0.5f * (zi - wi), x1i = -0.5f * (zr - wr);
+      const float p0 = x0r * x0r + x0i * x0i, p1 = x1r * x1r + x1i * x1i;
+      const float wl = a.mel_wlo[k], wh = a.mel_whi[k];
+      const int pk = k + (k >> 5);  // runs of neighbouring mels start ~32 bins apart at the top of the band
+      T[pk] = wl * p0;
+      T[kTStride + pk] = wh * p0;
+      T[2 * kTStride + pk] = wl * p1;
+      T[3 * kTStride + pk] = wh * p1;
+    }
   }
   __syncthreads();
   const int sel = tid >> 7, m = tid & 127;
@@ -389,8 +420,7 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(StftArgs a) {
   }
   const float dbv = 10.0f * log10f(fmaxf(1e-10f, s));  // librosa.power_to_db(ref=1, amin=1e-10)
   const int f = sel ? f1 : f0;
-  const bool valid = f < a.n_frames;
-  if (valid) a.db[((size_t)u * a.n_frames + f) * 128 + m] = dbv;
+  if (f < a.n_frames) a.db[((size_t)u * a.n_frames + f) * 128 + m] = dbv;
   const float wm = wave_max(dbv);
   if ((tid & 63) == 0) wmax[tid >> 6] = wm;
   __syncthreads();

@@ -33,4 +33,8 @@ struct lipasr_mlp {
   float* ws = nullptr;  // workspace
   size_t ws_floats = 0;
   size_t offLogits = 0, offProb = 0, offDzLast = 0, offG0 = 0, offG1 = 0, offG2 = 0, offPart = 0;
+  // weight-gradient GEMMs run on a forked side stream, concurrently with the dX / BatchNorm-backward chain
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork[LIPASR_MAX_LAYERS] = {};
+  hipEvent_t ev_dw[LIPASR_MAX_LAYERS] = {};
 };

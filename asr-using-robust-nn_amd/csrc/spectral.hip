@@ -35,6 +35,7 @@ constexpr int kSquarings = 40;
 //   p_mode 2: P_in = identity (R == n_in)    (single-layer model: P_out = W^T)
 // emit_gram: also write this block's partial Gram  sum_i P_out[:,i] P_out[:,i]^T  (fp64, R*R)
 // ---------------------------------------------------------------------------------------------
+template <int RM>  // compile-time bound on R: keeps the unrolled body (and the instruction footprint) small
 __global__ __launch_bounds__(256) void chain_step_kernel(const float* __restrict__ Pin, int p_mode,
                                                           const float* __restrict__ W, int n_rows, int n_in, int R,
                                                           float* __restrict__ Pout, int emit_gram,
@@ -67,25 +68,25 @@ __global__ __launch_bounds__(256) void chain_step_kernel(const float* __restrict
     }
   }
   const int RR = R * R;
-  double gacc[(kMaxR * kMaxR) / 64];
+  double gacc[(RM * RM + 63) / 64];
 #pragma unroll
-  for (int q = 0; q < (kMaxR * kMaxR) / 64; ++q) gacc[q] = 0.0;
+  for (int q = 0; q < (RM * RM + 63) / 64; ++q) gacc[q] = 0.0;
   __syncthreads();
 
   const bool vec = ((n_in & 3) == 0) && ((reinterpret_cast<uintptr_t>(W) & 15) == 0);
   for (int rr = 0; rr < kChainRowsPerWave; ++rr) {
     const int i = blockIdx.x * kChainRowsPerBlock + wave * kChainRowsPerWave + rr;
     const bool live = i < n_rows;  // wave-uniform
-    float acc[kMaxR];
+    float acc[RM];
 #pragma unroll
-    for (int r = 0; r < kMaxR; ++r) acc[r] = 0.0f;
+    for (int r = 0; r < RM; ++r) acc[r] = 0.0f;
     if (live) {
       const float* wrow = W + (size_t)i * n_in;
       if (vec) {
         for (int j = lane * 4; j < n_in; j += 256) {
           const float4 w = *reinterpret_cast<const float4*>(wrow + j);
 #pragma unroll
-          for (int r = 0; r < kMaxR; ++r) {
+          for (int r = 0; r < RM; ++r) {
             if (r < R) {
               const float4 p = *reinterpret_cast<const float4*>(Ps + r * n_in + j);
               acc[r] = fmaf(w.x, p.x, acc[r]);
@@ -99,30 +100,30 @@ __global__ __launch_bounds__(256) void chain_step_kernel(const float* __restrict
         for (int j = lane; j < n_in; j += 64) {
           const float w = wrow[j];
 #pragma unroll
-          for (int r = 0; r < kMaxR; ++r)
+          for (int r = 0; r < RM; ++r)
             if (r < R) acc[r] = fmaf(w, Ps[r * n_in + j], acc[r]);
         }
       }
     }
 #pragma unroll
-    for (int r = 0; r < kMaxR; ++r)
+    for (int r = 0; r < RM; ++r)
       if (r < R) acc[r] = wave_sum(acc[r]);
     if (live && lane == 0) {
 #pragma unroll
-      for (int r = 0; r < kMaxR; ++r)
+      for (int r = 0; r < RM; ++r)
         if (r < R) Pout[(size_t)r * n_rows + i] = acc[r];
     }
     if (emit_gram) {
       // publish this row's R sums to the wave's LDS slot, then each lane adds its Gram entries
       if (lane == 0) {
 #pragma unroll
-        for (int r = 0; r < kMaxR; ++r)
+        for (int r = 0; r < RM; ++r)
           if (r < R) rowsum[wave * kMaxR + r] = live ? acc[r] : 0.0f;
       }
       __builtin_amdgcn_wave_barrier();
       __threadfence_block();
 #pragma unroll
-      for (int q = 0; q < (kMaxR * kMaxR) / 64; ++q) {
+      for (int q = 0; q < (RM * RM + 63) / 64; ++q) {
         const int e = lane + 64 * q;
         if (e < RR) {
           const int a = e / R, b = e - a * R;
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(256) void chain_step_kernel(const float* __restrict
   }
   if (emit_gram) {
 #pragma unroll
-    for (int q = 0; q < (kMaxR * kMaxR) / 64; ++q) {
+    for (int q = 0; q < (RM * RM + 63) / 64; ++q) {
       const int e = lane + 64 * q;
       if (e < RR) gsm[wave * RR + e] = gacc[q];
     }
@@ -521,12 +522,17 @@ static int launch_chain(lipasr_ctx* h, const float* const* Ws, const int* rows, 
       set_error("product chain: Gram partials exceed scratch");
       return LIPASR_EUNSUPPORTED;
     }
-    if (lds > 48 * 1024)
-      LP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_step_kernel),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const float* Wk = (m == 1) ? Ws[0] : Ws[k];
-    hipLaunchKernelGGL(chain_step_kernel, dim3(blocks), dim3(256), lds, st, pin, p_mode, Wk, n_rows, n_in, R,
-                       cs->P[cur], emit, cs->gram);
+#define LP_CHAIN(RM)                                                                                          \
+  {                                                                                                           \
+    if (lds > 48 * 1024)                                                                                      \
+      LP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_step_kernel<RM>),                        \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                      \
+    hipLaunchKernelGGL(chain_step_kernel<RM>, dim3(blocks), dim3(256), lds, st, pin, p_mode, Wk, n_rows, n_in, R, \
+                       cs->P[cur], emit, cs->gram);                                                           \
+  }
+    if (R <= 12) LP_CHAIN(12) else if (R <= 20) LP_CHAIN(20) else LP_CHAIN(32)
+#undef LP_CHAIN
     LP_LAUNCH_CHECK();
     if (emit) *n_part_out = blocks;
     pin = cs->P[cur];

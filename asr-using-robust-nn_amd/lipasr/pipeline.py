@@ -7,6 +7,11 @@ Everything after the MFCC reads and writes fixed device buffers, so it is captur
 into HIP graphs (lipasr_graph_*) and replayed; Adam's step count, the dropout counter and all
 projection scalars live in device memory, so a replay needs no host value.  The MFCC kernels read the
 resident waveform pool in place and are launched eagerly (3 launches per step).
+
+Two HIP streams: the MFCC of batch i+1 (VALU/LDS-bound kernels) runs on its own stream while the
+classifier step of batch i (many short MFMA / latency-bound kernels) runs on the training stream; the
+feature and label buffers are double-buffered and hipEvents carry the two dependencies
+(features ready -> train; train done with a buffer -> MFCC may overwrite it).
 """
 from __future__ import annotations
 
@@ -38,23 +43,29 @@ class TrainPipeline:
         nf = 20 * self.L
         if model._widths[0] != nf:
             raise ValueError(f"model input width {model._widths[0]} != {nf}")
-        self.feats = torch.zeros(self.batch, nf, device=self.dev)
+        self._nbuf = 2  # feature/label buffers in flight (a third buys nothing: the two streams contend for CUs)
+        self._feats2 = [torch.zeros(self.batch, nf, device=self.dev) for _ in range(self._nbuf)]
+        self._labels2 = [torch.zeros(self.batch, model._n_classes, device=self.dev) for _ in range(self._nbuf)]
+        self.feats, self.labels = self._feats2[0], self._labels2[0]  # buffers of the most recent step
         self.x_adv = torch.zeros(self.batch, nf, device=self.dev) if pgd else None
-        self.labels = torch.zeros(self.batch, model._n_classes, device=self.dev)
         nl = len(model._blocks)
         self.norms = torch.zeros(nl + 1, device=self.dev)
         self.sigmas = torch.zeros(nl, device=self.dev)
         self.v_state = torch.zeros(sum(model._widths[1:]), device=self.dev)
         self._order = N.int_array(list(range(nl)))
         self._warm = False
-        self.stream = torch.cuda.Stream(device=self.dev)
+        self.stream = torch.cuda.Stream(device=self.dev)       # training stream (equal priorities measured best)
+        self.mfcc_stream = torch.cuda.Stream(device=self.dev)  # feature-extraction stream
+        self._ev_feat = [torch.cuda.Event() for _ in range(self._nbuf)]   # features of buffer b are ready
+        self._ev_free = [None] * self._nbuf                             # training has finished reading buffer b
+        self._i = 0
         self._graphs = {}
 
     # ---- pieces (all enqueue on the current stream)
-    def _attack_and_train(self, bsz):
+    def _attack_and_train(self, bsz, b):
         m = self.model
-        x = self.feats[:bsz]
-        y = self.labels[:bsz]
+        x = self._feats2[b][:bsz]
+        y = self._labels2[b][:bsz]
         if self.pgd:
             xa = self.x_adv[:bsz]
             xa.copy_(x)
@@ -94,27 +105,38 @@ class TrainPipeline:
     def step(self, waves, y_onehot):
         """waves: float32 device tensor [b, n_samp] (a view into a resident pool is fine), y_onehot [b, classes]."""
         bsz = waves.shape[0]
+        b = self._i % self._nbuf
+        self._i += 1
+        self.feats, self.labels = self._feats2[b], self._labels2[b]
+        with torch.cuda.stream(self.mfcc_stream):
+            if self._ev_free[b] is not None:
+                self.mfcc_stream.wait_event(self._ev_free[b])  # the step that last read this buffer is done
+            self.ex(waves, self.L, self.mean, self.scale, out=self._feats2[b][:bsz])
+            self._labels2[b][:bsz].copy_(y_onehot)
+            self._ev_feat[b].record(self.mfcc_stream)
         with torch.cuda.stream(self.stream):
             self._warm_start()
-            self.ex(waves, self.L, self.mean, self.scale, out=self.feats[:bsz])
-            self.labels[:bsz].copy_(y_onehot)
+            self.stream.wait_event(self._ev_feat[b])
             if not self.use_graph:
-                self._attack_and_train(bsz)
+                self._attack_and_train(bsz, b)
                 self.dp.allreduce_grads(self.model._grads)
                 self._update()
-                return
-            g = self._graphs.get(bsz)
-            if g is None:
-                # run once eagerly (also warms every kernel), then capture
-                if self.dp.world == 1:
-                    g = (self._capture(lambda: (self._attack_and_train(bsz), self._update())),)
-                else:
-                    g = (self._capture(self._attack_and_train, bsz), self._capture(self._update))
-                self._graphs[bsz] = g
-            N.check(N.lib.lipasr_graph_launch(self.h.h, g[0], N.stream_ptr()))
-            if len(g) == 2:
-                self.dp.allreduce_grads(self.model._grads)
-                N.check(N.lib.lipasr_graph_launch(self.h.h, g[1], N.stream_ptr()))
+            else:
+                g = self._graphs.get((bsz, b))
+                if g is None:
+                    if self.dp.world == 1:
+                        g = (self._capture(lambda: (self._attack_and_train(bsz, b), self._update())),)
+                    else:
+                        g = (self._capture(self._attack_and_train, bsz, b), self._capture(self._update))
+                    self._graphs[(bsz, b)] = g
+                N.check(N.lib.lipasr_graph_launch(self.h.h, g[0], N.stream_ptr()))
+                if len(g) == 2:
+                    self.dp.allreduce_grads(self.model._grads)
+                    N.check(N.lib.lipasr_graph_launch(self.h.h, g[1], N.stream_ptr()))
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+            self._ev_free[b] = ev
 
     def synchronize(self):
+        self.mfcc_stream.synchronize()
         self.stream.synchronize()
