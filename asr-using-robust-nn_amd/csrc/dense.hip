@@ -268,6 +268,186 @@ __global__ __launch_bounds__(64 * NW) void gemm_f32_kernel(GemmArgs g) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// LDS-tiled variant for the large GEMMs: one workgroup (512 threads, 8 wavefronts) = one 64x64 tile.  K advances
+// in 32-deep stages through a double-buffered LDS image stored k-major ([k][m] and [k][n], row stride 68
+// floats): MFMA operand reads are unit-stride ds_read_b32 (conflict-free) and every operand element is
+// fetched from L2 once per workgroup instead of once per 32x32 tile.  Wavefronts 0-3 take k 0..15 of each
+// stage for the four 32x32 quadrants, wavefronts 4-7 take k 16..31: two wavefronts per SIMD, so one's LDS
+// latency hides behind the other's MFMAs.  Global loads for stage t+1 are issued before the MFMAs of stage t
+// and written to the other LDS buffer afterwards: one barrier per stage.  The two K halves meet in LDS.
+// ---------------------------------------------------------------------------------------------
+constexpr int kLdsBK = 32, kLdsLD = 68;
+
+template <int MODE>  // 0: operand(i,k) = P[i*ld + k] (K contiguous), 1: P[k*ld + i]
+__device__ __forceinline__ float4 tile_fetch(const float* __restrict__ P, int ld, int i0, int i_real, int k0, int K,
+                                             bool ones_last, int i_last, int tid) {
+  float t[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool al = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(P) & 15) == 0);
+  if (MODE == 0) {
+    const int i = i0 + (tid >> 3);                     // 64 rows, 8 float4 (32 k) per row
+    const int kq = k0 + (tid & 7) * 4;
+    const float* p = P + (size_t)min(i, i_real - 1) * ld + kq;
+    if (kq + 3 < K && al) {
+      const float4 x = *reinterpret_cast<const float4*>(p);
+      t[0] = x.x; t[1] = x.y; t[2] = x.z; t[3] = x.w;
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) t[c] = (kq + c < K) ? p[c] : 0.0f;
+    }
+  } else {
+    const int k = k0 + (tid >> 4);                     // 32 k rows, 16 float4 (64 i) per row
+    const int iq = i0 + (tid & 15) * 4;
+    if (k < K) {
+      const float* p = P + (size_t)k * ld;
+      if (iq + 3 < i_real && al) {
+        const float4 x = *reinterpret_cast<const float4*>(p + iq);
+        t[0] = x.x; t[1] = x.y; t[2] = x.z; t[3] = x.w;
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int i = iq + c;
+          t[c] = (ones_last && i == i_last) ? 1.0f : p[min(i, i_real - 1)];
+        }
+      }
+    }
+  }
+  return make_float4(t[0], t[1], t[2], t[3]);
+}
+
+template <int MODE>
+__device__ __forceinline__ void tile_store(float* __restrict__ S, int tid, const float4 v) {
+  if (MODE == 0) {
+    const int i = tid >> 3, kq = (tid & 7) * 4;
+    S[(kq + 0) * kLdsLD + i] = v.x;
+    S[(kq + 1) * kLdsLD + i] = v.y;
+    S[(kq + 2) * kLdsLD + i] = v.z;
+    S[(kq + 3) * kLdsLD + i] = v.w;
+  } else {
+    const int k = tid >> 4, iq = (tid & 15) * 4;
+    *reinterpret_cast<float4*>(S + k * kLdsLD + iq) = v;
+  }
+}
+
+template <int AMODE, int BMODE>
+__global__ __launch_bounds__(512) void gemm_lds_kernel(GemmArgs g) {
+  constexpr int TS = 64;
+  __shared__ __attribute__((aligned(16))) float lds[2 * 2 * kLdsBK * kLdsLD];  // [buf][A|B][32][68]; reused as [2][64][64]
+  __shared__ float stat[8 * 16 * 8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int kh = wave >> 2, wi = (wave >> 1) & 1, wj = wave & 1;
+  const int m0 = blockIdx.y * TS, n0 = blockIdx.x * TS;
+  const int m_real = g.ones_row ? g.M - 1 : g.M;
+  const int nst = (g.K + kLdsBK - 1) / kLdsBK;
+  const bool ones = g.ones_row != 0;
+  f32x16 acc;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+  float4 ra = tile_fetch<AMODE>(g.A, g.lda, m0, m_real, 0, g.K, ones, g.M - 1, tid);
+  float4 rb = tile_fetch<BMODE>(g.B, g.ldb, n0, g.N, 0, g.K, false, 0, tid);
+  tile_store<AMODE>(lds, tid, ra);
+  tile_store<BMODE>(lds + kLdsBK * kLdsLD, tid, rb);
+  __syncthreads();
+  for (int t = 0; t < nst; ++t) {
+    const float* As = lds + (t & 1) * 2 * kLdsBK * kLdsLD + (16 * kh + h) * kLdsLD + 32 * wi + r;
+    const float* Bs = lds + (t & 1) * 2 * kLdsBK * kLdsLD + kLdsBK * kLdsLD + (16 * kh + h) * kLdsLD + 32 * wj + r;
+    if (t + 1 < nst) {
+      ra = tile_fetch<AMODE>(g.A, g.lda, m0, m_real, (t + 1) * kLdsBK, g.K, ones, g.M - 1, tid);
+      rb = tile_fetch<BMODE>(g.B, g.ldb, n0, g.N, (t + 1) * kLdsBK, g.K, false, 0, tid);
+    }
+    float av[8], bv[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      av[s] = As[2 * s * kLdsLD];
+      bv[s] = Bs[2 * s * kLdsLD];
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc, 0, 0, 0);
+    if (t + 1 < nst) {
+      float* An = lds + ((t + 1) & 1) * 2 * kLdsBK * kLdsLD;
+      tile_store<AMODE>(An, tid, ra);
+      tile_store<BMODE>(An + kLdsBK * kLdsLD, tid, rb);
+    }
+    __syncthreads();
+  }
+  // accumulators -> LDS as two 64x64 partial tiles (one per K half), then the shared epilogue shape
+  float* red = lds;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int row = 32 * wi + (q & 3) + 8 * (q >> 2) + 4 * h;
+    red[kh * TS * TS + row * TS + 32 * wj + r] = acc[q];
+  }
+  __syncthreads();
+  const bool stats = (g.epi == EPI_BIAS_RELU_STATS) || (g.epi == EPI_DH_STATS);
+  const int step = g.drop.step_dev ? *g.drop.step_dev : 0;
+  const int tcol = tid & 15, trow = tid >> 4;
+  const int c4 = tcol * 4, gn = n0 + c4;
+  float cs1[4] = {0.f, 0.f, 0.f, 0.f}, cs2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int row = trow + 32 * pass;
+    float4 s = *reinterpret_cast<const float4*>(red + row * TS + c4);
+    const float4 s2 = *reinterpret_cast<const float4*>(red + TS * TS + row * TS + c4);
+    s.x += s2.x; s.y += s2.y; s.z += s2.z; s.w += s2.w;
+    const int gm = m0 + row;
+    if (gm < g.M) {
+      const float v[4] = {s.x, s.y, s.z, s.w};
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float t1 = 0.0f, t2 = 0.0f;
+        o[e] = (gn + e < g.N) ? epilogue_elem(g, step, gm, gn + e, v[e], t1, t2) : 0.0f;
+        cs1[e] += t1;
+        cs2[e] += t2;
+      }
+      float* crow;
+      if (g.ones_row && gm == g.M - 1) crow = g.extra_out;
+      else crow = (g.epi == EPI_SIGNSTEP ? g.x_adv : g.C) + (size_t)gm * g.ldc;
+      if (gn + 3 < g.N && ((g.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(crow) & 15) == 0)) {
+        *reinterpret_cast<float4*>(crow + gn) = make_float4(o[0], o[1], o[2], o[3]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (gn + e < g.N) crow[gn + e] = o[e];
+      }
+    }
+  }
+  if (stats) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      cs1[e] += __shfl_xor(cs1[e], 16, 64); cs1[e] += __shfl_xor(cs1[e], 32, 64);
+      cs2[e] += __shfl_xor(cs2[e], 16, 64); cs2[e] += __shfl_xor(cs2[e], 32, 64);
+    }
+    if (lane < 16) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        stat[(wave * 16 + lane) * 8 + e] = cs1[e];
+        stat[(wave * 16 + lane) * 8 + 4 + e] = cs2[e];
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * TS) {
+      const int which = tid / TS, col = tid % TS;
+      const int l4 = col >> 2, e = col & 3;
+      float t = 0.0f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) t += stat[(w * 16 + l4) * 8 + which * 4 + e];
+      if (n0 + col < g.N) g.part[((size_t)which * gridDim.y + blockIdx.y) * g.N + n0 + col] = t;
+    }
+  }
+}
+
+static int g_gemm_mode = 0;  // 0 auto, 1 split-K kernel only, 2 LDS kernel wherever it is legal (profiling knob)
+
+static bool use_lds_gemm(int M, int N, int K) {
+  if (g_gemm_mode == 1) return false;
+  const bool legal = M >= 64 && N >= 64 && K >= 32;
+  if (g_gemm_mode == 2) return legal;
+  const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
+  return legal && tiles >= 224;  // measured on MI355X (scratch/time_gemm.py): it wins only when >= ~one tile per CU
+}
+
 template <int AMODE, int BMODE, int NW>
 static void launch_gemm_t(const GemmArgs& g, hipStream_t st) {
   const dim3 grid((g.N + 31) / 32, (g.M + 31) / 32);
@@ -288,6 +468,15 @@ static int launch_gemm(int amode, int bmode, const GemmArgs& g, hipStream_t st) 
   }
   // Few output tiles and a long K (the dW GEMMs of the narrow layers, K = batch): 16 wavefronts split K so that
   // the serial chain of chunk loads per wavefront stays short.  Not for the *_STATS epilogues (never needed there).
+  if (use_lds_gemm(g.M, g.N, g.K)) {
+    const dim3 grid((g.N + 63) / 64, (g.M + 63) / 64);
+    if (amode == 0 && bmode == 0) hipLaunchKernelGGL((gemm_lds_kernel<0, 0>), grid, dim3(512), 0, st, g);
+    else if (amode == 0 && bmode == 1) hipLaunchKernelGGL((gemm_lds_kernel<0, 1>), grid, dim3(512), 0, st, g);
+    else if (amode == 1 && bmode == 0) hipLaunchKernelGGL((gemm_lds_kernel<1, 0>), grid, dim3(512), 0, st, g);
+    else hipLaunchKernelGGL((gemm_lds_kernel<1, 1>), grid, dim3(512), 0, st, g);
+    LP_LAUNCH_CHECK();
+    return LIPASR_OK;
+  }
   const long tiles = (long)((g.N + 31) / 32) * ((g.M + 31) / 32);
   const bool deep = tiles <= 192 && g.K >= 512 && g.epi != EPI_BIAS_RELU_STATS && g.epi != EPI_DH_STATS;
   if (deep) {
@@ -305,7 +494,8 @@ static int launch_gemm(int amode, int bmode, const GemmArgs& g, hipStream_t st) 
   return LIPASR_OK;
 }
 
-static int stats_row_tiles(int M, int N) { (void)N; return (M + 31) / 32; }
+// row tiles of the *_STATS epilogues: must follow the kernel choice of launch_gemm for the same (M, N, K)
+static int stats_row_tiles(int M, int N, int K) { return use_lds_gemm(M, N, K) ? (M + 63) / 64 : (M + 31) / 32; }
 
 static GemmArgs gemm_args(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
                           int epi) {
@@ -549,6 +739,11 @@ using namespace lipasr;
 // plan
 // ------------------------------------------------------------------------------------------------
 extern "C" {
+
+int lipasr_debug_gemm_mode(int mode) {
+  g_gemm_mode = mode;
+  return LIPASR_OK;
+}
 
 int lipasr_gemm_f32(lipasr_handle_t h, int transA, int transB, int M, int N, int K, const float* A, int lda,
                     const float* B, int ldb, float* C, int ldc, lipasr_stream_t stream) {
@@ -796,7 +991,7 @@ int lipasr_mlp_train_fwd_bwd(lipasr_mlp_t m, const float* params, float* bnstate
       memset(&b, 0, sizeof(b));
       b.a = ws + L.offA; b.h = ws + L.offH; b.B = batch; b.N = L.n_out; b.has_bn = L.bn ? 1 : 0;
       b.part = part;
-      b.n_tiles = stats_row_tiles(batch, L.n_out);
+      b.n_tiles = stats_row_tiles(batch, L.n_out, L.n_in);
       if (L.bn) {
         b.gamma = params + L.offg; b.beta = params + L.offbe;
         b.mmean = bnstate + L.offmm; b.mvar = bnstate + L.offmv;
@@ -855,7 +1050,7 @@ int lipasr_mlp_train_fwd_bwd(lipasr_mlp_t m, const float* params, float* bnstate
       memset(&b, 0, sizeof(b));
       b.g = out1; b.a = ws + P.offA; b.dz = out2; b.B = batch; b.N = P.n_out;
       b.part = part;
-      b.n_tiles = stats_row_tiles(batch, P.n_out);
+      b.n_tiles = stats_row_tiles(batch, P.n_out, L.n_out);
       b.gamma = params + P.offg; b.save_mean = ws + P.offMean;
       b.dgamma = grads + P.offg; b.dbeta = grads + P.offbe;
       const dim3 grid((P.n_out + 127) / 128, (batch + kApplyRows - 1) / kApplyRows);

@@ -90,6 +90,7 @@ PROTOTYPES = {
     "lipasr_mfcc_profile_end": (i32, [c_h, C.POINTER(f32), PI]),
     "lipasr_add_noise_f32": (i32, [c_h, c_f, i32, i32, i32, f32, f32, u64, c_s]),
     "lipasr_debug_set": (i32, [c_h, i32, i32]),
+    "lipasr_debug_gemm_mode": (i32, [i32]),
     "lipasr_debug_table": (i32, [i32, i32, C.POINTER(f32), i32]),
 }
 

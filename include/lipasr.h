@@ -266,6 +266,10 @@ int lipasr_add_noise_f32(lipasr_handle_t h, float* y, int batch, int n, int mode
  * wrong results and exist to time the remaining stages; bit2 selects the VALU resampler instead of the MFMA one). */
 int lipasr_debug_set(lipasr_handle_t h, int key, int value);
 
+/* Profiling knob: GEMM kernel choice. 0 = automatic, 1 = split-K register kernel only, 2 = LDS-tiled kernel
+ * wherever it is legal. */
+int lipasr_debug_gemm_mode(int mode);
+
 /* Host-only (no GPU needed): copies one constant table, exactly as the kernels read it, into `out`
  * and returns its element count (negative = error); out may be NULL to query the size.
  * which: 0 Hann[2048]; 1 DCT[20*128]; 2 dense mel filter bank[128*1025]; 3 polyphase resampling taps
