@@ -24,7 +24,7 @@ namespace lipasr {
 constexpr double kEps = 2.220446049250313e-16;  // np.spacing(1), Constraints.py:25,167
 constexpr int kMaxR = 32;
 constexpr int kMaxOrder = 64;
-constexpr int kChainRowsPerWave = 2;
+constexpr int kChainRowsPerWave = 1;
 constexpr int kChainRowsPerBlock = 4 * kChainRowsPerWave;
 constexpr int kSquarings = 40;
 
@@ -46,6 +46,16 @@ __global__ __launch_bounds__(256) void chain_step_kernel(const float* __restrict
   double* gsm = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(rowsum + 4 * kMaxR) + 7) & ~uintptr_t(7));  // [4][R*R]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int total = R * n_in;
+  // this wavefront's weight row starts its trip from L2/HBM before P is staged (first 1024 columns in registers)
+  const bool vec = ((n_in & 3) == 0) && ((reinterpret_cast<uintptr_t>(W) & 15) == 0);
+  const int i_pref = blockIdx.x * kChainRowsPerBlock + wave * kChainRowsPerWave;
+  float4 wpre[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int j = lane * 4 + 256 * t;
+    wpre[t] = (vec && i_pref < n_rows && j < n_in) ? *reinterpret_cast<const float4*>(W + (size_t)i_pref * n_in + j)
+                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   if (p_mode == 0) {
     if ((total & 3) == 0 && (reinterpret_cast<uintptr_t>(Pin) & 15) == 0) {
       const float4* src = reinterpret_cast<const float4*>(Pin);
@@ -73,7 +83,6 @@ __global__ __launch_bounds__(256) void chain_step_kernel(const float* __restrict
   for (int q = 0; q < (RM * RM + 63) / 64; ++q) gacc[q] = 0.0;
   __syncthreads();
 
-  const bool vec = ((n_in & 3) == 0) && ((reinterpret_cast<uintptr_t>(W) & 15) == 0);
   for (int rr = 0; rr < kChainRowsPerWave; ++rr) {
     const int i = blockIdx.x * kChainRowsPerBlock + wave * kChainRowsPerWave + rr;
     const bool live = i < n_rows;  // wave-uniform
@@ -83,8 +92,11 @@ __global__ __launch_bounds__(256) void chain_step_kernel(const float* __restrict
     if (live) {
       const float* wrow = W + (size_t)i * n_in;
       if (vec) {
-        for (int j = lane * 4; j < n_in; j += 256) {
-          const float4 w = *reinterpret_cast<const float4*>(wrow + j);
+        int tt = 0;
+        for (int j = lane * 4; j < n_in; j += 256, ++tt) {
+          float4 w;
+          if (rr == 0 && tt < 4) w = (tt == 0) ? wpre[0] : (tt == 1) ? wpre[1] : (tt == 2) ? wpre[2] : wpre[3];
+          else w = *reinterpret_cast<const float4*>(wrow + j);
 #pragma unroll
           for (int r = 0; r < RM; ++r) {
             if (r < R) {
