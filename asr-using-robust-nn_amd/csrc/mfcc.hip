@@ -161,7 +161,22 @@ __global__ __launch_bounds__(64 * kRsWaves) void resample_mfma_kernel(const floa
   extern __shared__ __attribute__((aligned(16))) float xs[];  // [32][kRsStride]; xs[i][t] = x_i[down*q - 64 + t]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, h = lane >> 5;
-  const int u0 = blockIdx.y * 32, q = blockIdx.x;
+  // XCD-aware map (speed only, see stft_mel_kernel): blocks L, L+8, ... share an L2 and take consecutive q-blocks of
+  // one 32-clip tile, whose input windows overlap by 127 of 447 samples
+  int ut, q;
+  {
+    const int nqb = gridDim.x, L = blockIdx.y * gridDim.x + blockIdx.x;
+    const int full = (gridDim.y / 8) * 8 * nqb;
+    if (L < full) {
+      const int chunk = L >> 3;
+      ut = (chunk / nqb) * 8 + (L & 7);
+      q = chunk % nqb;
+    } else {
+      ut = blockIdx.y;
+      q = blockIdx.x;
+    }
+  }
+  const int u0 = ut * 32;
   const int base = down * q - left;  // = down*q - 64: one sample before the first tap, 16-byte aligned
   constexpr int kVecPerRow = (kRsStride - 1) / 4;  // 120 float4 = 480 floats per row
   const bool vec = ((n_samp & 3) == 0) && ((down & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
@@ -342,8 +357,24 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(StftArgs a) {
   __shared__ __attribute__((aligned(16))) float2 buf[kFftLds];  // ONE buffer: 17 kB per workgroup
   __shared__ float wmax[4];
   const int tid = threadIdx.x;
-  const int u = blockIdx.y;
-  const int f0 = blockIdx.x * 2, f1 = f0 + 1;
+  // XCD-aware block -> (clip, frame pair) map (speed only): workgroups are dealt round-robin over the 8 XCDs, so
+  // blocks L, L+8, L+16, ... share an L2.  Giving those to consecutive frame pairs of ONE clip lets the 75 %
+  // overlap between neighbouring frames hit in that L2 instead of being re-fetched by four different XCDs.
+  int u, fp;
+  {
+    const int npairs = gridDim.x, L = blockIdx.y * gridDim.x + blockIdx.x;
+    const int nb = gridDim.y;
+    const int full = (nb / 8) * 8 * npairs;  // blocks covered by complete groups of 8 clips
+    if (L < full) {
+      const int xcd = L & 7, chunk = L >> 3;
+      u = (chunk / npairs) * 8 + xcd;
+      fp = chunk % npairs;
+    } else {
+      u = blockIdx.y;
+      fp = blockIdx.x;
+    }
+  }
+  const int f0 = fp * 2, f1 = f0 + 1;
   const bool has1 = f1 < a.n_frames;
   const float* yu = a.y + (size_t)u * a.n_y;
   // frame f covers padded positions [512 f, 512 f + 2048) = y positions [512 f - 1024, ...)

@@ -202,8 +202,17 @@ def main():
     stage_ms = ms["resample"] + ms["stft_mel"] + ms["dct"]
     dom = max(("resample", "stft_mel", "dct"), key=lambda k: ms[k])
     achieved = MFCC_BYTES_PER_UTT * batch / (stage_ms * 1e-3) / 1e9 if stage_ms > 0 else 0.0
+    # HBM traffic of the stage per launch: PMC counters cannot be read from inside this process, so the value is
+    # the committed rocprofv3 measurement of the same three kernels (profiles/r02_mfcc_pmc.json: separate
+    # --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per MI355X_MICROARCH.md), scaled to this batch.
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_mfcc_pmc.json")) as f:
+            traffic = round(json.load(f)["after_xcd_mapping"]["stage_bytes_per_utt"] * batch)
+    except Exception:
+        pass
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": None, "stage": "MFCC (K1 = resample + stft_mel + dct kernels)", "dominant_kernel": dom + "_kernel",
+                "traffic": traffic, "traffic_source": "profiles/r02_mfcc_pmc.json (rocprofv3 --pmc, per launch, scaled by batch)", "stage": "MFCC (K1 = resample + stft_mel + dct kernels)", "dominant_kernel": dom + "_kernel",
                 "algorithmic_bytes_per_utt": MFCC_BYTES_PER_UTT, "units_per_launch": batch,
                 "kernel_ms": {k: round(ms[k], 4) for k in ("resample", "stft_mel", "dct")},
                 "fp32_flop_frac": round(MFCC_FLOP_PER_UTT * batch / (stage_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 5) if stage_ms > 0 else 0.0,
