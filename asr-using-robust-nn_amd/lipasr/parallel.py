@@ -59,12 +59,26 @@ class DataParallel:
     def broadcast(self, *tensors, src=0):
         if self.world > 1:
             for t in tensors:
-                dist.broadcast(t, src=src, group=self.group)
+                if self._host_staged(t):
+                    tmp = t.cpu()
+                    dist.broadcast(tmp, src=src, group=self.group)
+                    t.copy_(tmp)
+                else:
+                    dist.broadcast(t, src=src, group=self.group)
+
+    def _host_staged(self, t):
+        # gloo cannot reduce device tensors: used only by the single-GPU rehearsal of the DP path (tests)
+        return t.is_cuda and dist.get_backend(self.group) == "gloo"
 
     def allreduce_grads(self, flat):
         """The one collective of a step: in-place SUM over the flat gradient buffer."""
         if self.world > 1:
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            if self._host_staged(flat):
+                tmp = flat.cpu()
+                dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=self.group)
+                flat.copy_(tmp)
+            else:
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         return flat
 
     def train_step(self, replica, xb, yb, global_batch=None, **kw):
@@ -88,8 +102,9 @@ class DataParallel:
         """max |flat - rank0's flat| over ranks (0.0 when the replicas are in sync)."""
         if self.world == 1:
             return 0.0
-        ref = flat.clone()
+        mine = flat.cpu() if self._host_staged(flat) else flat
+        ref = mine.clone()
         dist.broadcast(ref, src=0, group=self.group)
-        d = (flat - ref).abs().max().reshape(1)
+        d = (mine - ref).abs().max().reshape(1)
         dist.all_reduce(d, op=dist.ReduceOp.MAX, group=self.group)
         return float(d.item())
