@@ -102,16 +102,21 @@ class TrainPipeline:
                                                        N.stream_ptr()))
             self._warm = True
 
-    def step(self, waves, y_onehot):
-        """waves: float32 device tensor [b, n_samp] (a view into a resident pool is fine), y_onehot [b, classes]."""
-        bsz = waves.shape[0]
+    def step(self, waves, y_onehot, features=None):
+        """waves: float32 device tensor [b, n_samp] (a view into a resident pool is fine), y_onehot [b, classes].
+        features: pre-extracted, already standardised [b, 20*L] features instead of waveforms (BASELINE config 2,
+        the reference's own train_constraints.py flow); the MFCC stage is skipped."""
+        bsz = (features if features is not None else waves).shape[0]
         b = self._i % self._nbuf
         self._i += 1
         self.feats, self.labels = self._feats2[b], self._labels2[b]
         with torch.cuda.stream(self.mfcc_stream):
             if self._ev_free[b] is not None:
                 self.mfcc_stream.wait_event(self._ev_free[b])  # the step that last read this buffer is done
-            self.ex(waves, self.L, self.mean, self.scale, out=self._feats2[b][:bsz])
+            if features is not None:
+                self._feats2[b][:bsz].copy_(features)
+            else:
+                self.ex(waves, self.L, self.mean, self.scale, out=self._feats2[b][:bsz])
             self._labels2[b][:bsz].copy_(y_onehot)
             self._ev_feat[b].record(self.mfcc_stream)
         with torch.cuda.stream(self.stream):

@@ -119,9 +119,16 @@ def run_config(args, batch, rank, world, device, steps, warmup, profile):
     pipe = TrainPipeline(model, batch=batch, rho=0.1, constraint=args.constraint, affine=(sc.mean_, sc.scale_), pgd=pgd, dp=dp,
                          use_graph=not args.no_graph)
 
+    feat_pool = None
+    if args.pre_extracted:
+        feat_pool = torch.cat([ex(waves[i * batch:(i + 1) * batch], 44, sc.mean_, sc.scale_) for i in range(n_batches)])
+
     def one(i):
         s = (i % n_batches) * batch
-        pipe.step(waves[s:s + batch], y[s:s + batch])
+        if feat_pool is not None:
+            pipe.step(None, y[s:s + batch], features=feat_pool[s:s + batch])
+        else:
+            pipe.step(waves[s:s + batch], y[s:s + batch])
 
     for i in range(warmup):
         one(i)
@@ -129,7 +136,7 @@ def run_config(args, batch, rank, world, device, steps, warmup, profile):
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    if profile:
+    if profile and not args.pre_extracted:
         N.check(N.lib.lipasr_mfcc_profile_begin(pipe.h.h, steps))
     tid = C.c_int()
     N.check(N.lib.lipasr_timer_create(pipe.h.h, C.byref(tid)))
@@ -149,7 +156,9 @@ def run_config(args, batch, rank, world, device, steps, warmup, profile):
     N.check(N.lib.lipasr_timer_elapsed_ms(pipe.h.h, tid.value, C.byref(ev_ms)))
     extras = {"event_ms_per_step": ev_ms.value / steps, "final_norm": float(pipe.norms[-1].item()) if args.constraint == "product" else None,
               "loss": float(model._loss_rows[:batch].mean().item())}
-    if profile:
+    if profile and args.pre_extracted:
+        extras["mfcc_ms"] = {"resample": 0.0, "stft_mel": 0.0, "dct": 0.0, "calls": 0}
+    elif profile:
         ms3 = (C.c_float * 3)()
         n = C.c_int()
         N.check(N.lib.lipasr_mfcc_profile_end(pipe.h.h, ms3, C.byref(n)))
@@ -168,6 +177,7 @@ def main():
     ap.add_argument("--pgd", type=int, default=0, help="PGD iterations per batch (config 5 uses 20)")
     ap.add_argument("--pgd-eps", type=float, default=0.5)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--pre-extracted", action="store_true", help="BASELINE config 2: train from resident (N,880) features, no MFCC stage")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--skip-b512", action="store_true")
     args = ap.parse_args()
@@ -217,13 +227,19 @@ def main():
                 "kernel_ms": {k: round(ms[k], 4) for k in ("resample", "stft_mel", "dct")},
                 "fp32_flop_frac": round(MFCC_FLOP_PER_UTT * batch / (stage_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 5) if stage_ms > 0 else 0.0,
                 "note": "stage is fp32-compute-bound (8.7 MFLOP/utt vs 67.5 kB/utt): see DESIGN.md"}
+    if args.pre_extracted:
+        tf = TRAIN_FLOP_PER_UTT * batch / (ex["event_ms_per_step"] * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "achieved": round(tf, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP32_PEAK_TFLOPS, 5),
+                    "traffic": None, "stage": "dense classifier train step (v_mfma_f32_32x32x2_f32, exact fp32)",
+                    "algorithmic_flop_per_utt": TRAIN_FLOP_PER_UTT, "units_per_launch": batch,
+                    "note": "whole step incl. BatchNorm, Adam and projection kernels; GEMM-only time is in profiles/"}
     out = {"metric": "utterances/sec (train, 1 s@16 kHz)", "value": round(value, 1), "unit": "utterances/sec", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": "raw 16 kHz waveform -> on-GPU MFCC -> Lipschitz-constrained MLP train step "
-                                  "(Adam+NonNeg, simple_norm_constraint rho=0.1)" + (f" + PGD-{args.pgd} adversarial inner loop" if args.pgd else "")
+           "config": {"workload": ("pre-extracted standardised (N,880) MFCC features" if args.pre_extracted else "raw 16 kHz waveform -> on-GPU MFCC")
+                                  + " -> Lipschitz-constrained MLP train step (Adam+NonNeg, simple_norm_constraint rho=0.1)" + (f" + PGD-{args.pgd} adversarial inner loop" if args.pgd else "")
                                   + (", data-parallel RCCL gradient all-reduce" if world > 1 else ", 1xMI355X"),
-                      "baseline_config": 5 if args.pgd else (4 if world > 1 else 3), "global_batch": global_batch, "per_gpu_batch": batch,
+                      "baseline_config": 5 if args.pgd else (2 if args.pre_extracted else (4 if world > 1 else 3)), "global_batch": global_batch, "per_gpu_batch": batch,
                       "clip": "1 s @ 16 kHz fp32", "parallelism": f"dp{world}", "hip_graph": not args.no_graph},
            "roofline": roofline,
            "mlp_tflops": round(TRAIN_FLOP_PER_UTT * batch / max(1e-9, (ex["event_ms_per_step"] - stage_ms) * 1e-3) / 1e12, 3),
