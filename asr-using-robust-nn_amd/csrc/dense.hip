@@ -152,14 +152,14 @@ __device__ __forceinline__ float epilogue_elem(const GemmArgs& g, int step, int 
 // One workgroup = one 32x32 output tile; its NW wavefronts (4, or 16 for small outputs with a long K) split K
 // in 16-deep chunks, round-robin.  Operand fragments go global/L2 -> VGPR directly, one chunk ahead of the MFMAs.
 template <int AMODE, int BMODE, int NW>
-__global__ __launch_bounds__(64 * NW) void gemm_f32_kernel(GemmArgs g) {
+__device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const int by, const int n_row_tiles) {
   constexpr int TS = 32;
   constexpr int TPR = 8;                       // threads per output row (one float4 each)
   extern __shared__ __attribute__((aligned(16))) float red[];  // [NW][32][32] + stats [4][8][8]
   float* stat = red + NW * TS * TS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int m0 = blockIdx.y * TS, n0 = blockIdx.x * TS;
+  const int m0 = by * TS, n0 = bx * TS;
   const int nch = (g.K + 15) >> 4;
   const bool vecA = (AMODE == 0) && ((g.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0);
   const bool vecB = (BMODE == 0) && ((g.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0);
@@ -263,9 +263,34 @@ __global__ __launch_bounds__(64 * NW) void gemm_f32_kernel(GemmArgs g) {
       float t = 0.0f;
 #pragma unroll
       for (int w = 0; w < 4; ++w) t += stat[(w * TPR + l4) * 8 + which * 4 + e];
-      if (n0 + col < g.N) g.part[((size_t)which * gridDim.y + blockIdx.y) * g.N + n0 + col] = t;
+      if (n0 + col < g.N) g.part[((size_t)which * n_row_tiles + by) * g.N + n0 + col] = t;
     }
   }
+}
+
+template <int AMODE, int BMODE, int NW>
+__global__ __launch_bounds__(64 * NW) void gemm_f32_kernel(GemmArgs g) {
+  gemm_tile<AMODE, BMODE, NW>(g, blockIdx.x, blockIdx.y, gridDim.y);
+}
+
+// Several independent GEMMs of one (AMODE, BMODE) in ONE launch: the six weight-gradient GEMMs of a training step
+// (outputs from 880x1024 down to 64x10, all with K = batch) fill the chip together instead of running as six
+// mostly latency-bound launches.  Block b belongs to the problem whose tile range contains it.
+constexpr int kMaxGroup = 8;
+struct GemmGroup {
+  int n;
+  int tile_start[kMaxGroup + 1];
+  GemmArgs g[kMaxGroup];
+};
+
+template <int AMODE, int BMODE, int NW>
+__global__ __launch_bounds__(64 * NW) void gemm_f32_grouped_kernel(GemmGroup grp) {
+  int p = 0;
+  while (p + 1 < grp.n && (int)blockIdx.x >= grp.tile_start[p + 1]) ++p;
+  const GemmArgs& g = grp.g[p];
+  const int local = blockIdx.x - grp.tile_start[p];
+  const int ntx = (g.N + 31) / 32;
+  gemm_tile<AMODE, BMODE, NW>(g, local % ntx, local / ntx, (g.M + 31) / 32);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -436,6 +461,30 @@ __global__ __launch_bounds__(512) void gemm_lds_kernel(GemmArgs g) {
       if (n0 + col < g.N) g.part[((size_t)which * gridDim.y + blockIdx.y) * g.N + n0 + col] = t;
     }
   }
+}
+
+// launches up to kMaxGroup weight-gradient style GEMMs (AMODE 1, BMODE 1) as one grid
+static int launch_gemm_group_tn(const GemmArgs* gs, int n, hipStream_t st) {
+  int done = 0;
+  while (done < n) {
+    GemmGroup grp;
+    memset(&grp, 0, sizeof(grp));
+    int k = 0, tiles = 0;
+    for (; k < kMaxGroup && done + k < n; ++k) {
+      const GemmArgs& g = gs[done + k];
+      if (g.M <= 0 || g.N <= 0 || g.K <= 0) { set_error("grouped gemm: empty problem"); return LIPASR_EINVAL; }
+      grp.g[k] = g;
+      grp.tile_start[k] = tiles;
+      tiles += ((g.N + 31) / 32) * ((g.M + 31) / 32);
+    }
+    grp.n = k;
+    grp.tile_start[k] = tiles;
+    const size_t lds = (size_t)(4 * 32 * 32 + 4 * 8 * 8) * sizeof(float);
+    hipLaunchKernelGGL((gemm_f32_grouped_kernel<1, 1, 4>), dim3(tiles), dim3(256), lds, st, grp);
+    LP_LAUNCH_CHECK();
+    done += k;
+  }
+  return LIPASR_OK;
 }
 
 static int g_gemm_mode = 0;  // 0 auto, 1 split-K kernel only, 2 LDS kernel wherever it is legal (profiling knob)
@@ -796,6 +845,7 @@ int lipasr_mlp_create(lipasr_handle_t h, int n_layers, const int* widths, const 
       else L.offH = L.offA;
       L.offMean = wo; wo = align4(wo + 2 * (size_t)L.n_out);
     }
+    L.offDz = wo; wo = align4(wo + (size_t)max_batch * L.n_out);
   }
   m->n_params = po;
   m->n_state = so;
@@ -816,15 +866,6 @@ int lipasr_mlp_create(lipasr_handle_t h, int n_layers, const int* widths, const 
     return LIPASR_ENOMEM;
   }
   (void)hipMemset(m->ws, 0, wo * sizeof(float));
-  bool ok = hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) == hipSuccess;
-  for (int l = 0; l < n_layers && ok; ++l)
-    ok = hipEventCreateWithFlags(&m->ev_fork[l], hipEventDisableTiming) == hipSuccess &&
-         hipEventCreateWithFlags(&m->ev_dw[l], hipEventDisableTiming) == hipSuccess;
-  if (!ok) {
-    (void)lipasr_mlp_destroy(m);
-    set_error("lipasr_mlp_create: side stream / event creation failed");
-    return LIPASR_EHIP;
-  }
   *out = m;
   return LIPASR_OK;
 }
@@ -833,11 +874,6 @@ int lipasr_mlp_destroy(lipasr_mlp_t m) {
   LP_CHECK_ARG(m != nullptr, "lipasr_mlp_destroy: null plan");
   DeviceGuard g(m->ctx->device);
   if (m->ws) (void)hipFree(m->ws);
-  for (int l = 0; l < LIPASR_MAX_LAYERS; ++l) {
-    if (m->ev_fork[l]) (void)hipEventDestroy(m->ev_fork[l]);
-    if (m->ev_dw[l]) (void)hipEventDestroy(m->ev_dw[l]);
-  }
-  if (m->side) (void)hipStreamDestroy(m->side);
   delete m;
   return LIPASR_OK;
 }
@@ -1012,30 +1048,16 @@ int lipasr_mlp_train_fwd_bwd(lipasr_mlp_t m, const float* params, float* bnstate
                      (float*)nullptr);
   LP_LAUNCH_CHECK();
 
-  // ---- backward.  gin = gradient at layer l's pre-activation.  Three rotating buffers: the dX GEMM reads
-  // gin and writes the next buffer, the BatchNorm-backward apply writes the one after.
-  float* G[3] = {ws + m->offG0, ws + m->offG1, ws + m->offG2};
-  const float* gin = ws + m->offDzLast;
-  int cur = 2;  // so that the first dX output lands in G[0]
-  for (int l = Lc - 1; l >= 0; --l) {
+  // ---- backward.  The dX chain runs first, layer by layer (dX GEMM fused with the dropout backward and the
+  // BatchNorm column sums, then the BatchNorm/ReLU backward apply), keeping every layer's pre-activation gradient;
+  // all weight gradients then come from ONE grouped launch.
+  float* tmp = ws + m->offG0;
+  for (int l = Lc - 1; l >= 1; --l) {
     const MlpLayer& L = m->L[l];
-    const float* lin = (l == 0) ? x : (ws + m->L[l - 1].offH);
-    // [dW ; db] = [lin ; 1]^T[n_in+1][B] * gin[B][n_out]: the all-ones row yields the bias gradient.
-    // Forked onto the side stream: it only feeds the optimizer, the dX chain below does not wait for it.
-    GemmArgs gw = gemm_args(lin, L.n_in, gin, L.n_out, grads + L.offW, L.n_out, L.n_in + 1, L.n_out, batch, EPI_STORE);
-    gw.ones_row = 1;
-    gw.extra_out = grads + L.offb;
-    LP_HIP(hipEventRecord(m->ev_fork[l], st));
-    LP_HIP(hipStreamWaitEvent(m->side, m->ev_fork[l], 0));
-    rc = launch_gemm(1, 1, gw, m->side);
-    if (rc != LIPASR_OK) return rc;
-    LP_HIP(hipEventRecord(m->ev_dw[l], m->side));
-    if (l == 0) break;
-    // the dX GEMM below overwrites the buffer that held layer l+1's gin, which dW(l+1) may still be reading
-    if (l + 1 < Lc) LP_HIP(hipStreamWaitEvent(st, m->ev_dw[l + 1], 0));
     const MlpLayer& P = m->L[l - 1];
-    // dh_prev[B][n_in] = gin[B][n_out] * W^T, fused with the backward of Dropout (and the BN column sums)
-    float* out1 = G[(cur + 1) % 3];
+    const float* gin = (l == Lc - 1) ? (ws + m->offDzLast) : (ws + L.offDz);
+    // dh_prev[B][n_in] = gin[B][n_out] * W^T
+    float* out1 = P.bn ? tmp : (ws + P.offDz);
     GemmArgs gx = gemm_args(gin, L.n_out, params + L.offW, L.n_out, out1, L.n_in, batch, L.n_in, L.n_out,
                             P.bn ? EPI_DH_STATS : EPI_DZ_NOBN);
     gx.aux = ws + P.offA;
@@ -1045,10 +1067,9 @@ int lipasr_mlp_train_fwd_bwd(lipasr_mlp_t m, const float* params, float* bnstate
     rc = launch_gemm(0, 0, gx, st);
     if (rc != LIPASR_OK) return rc;
     if (P.bn) {
-      float* out2 = G[(cur + 2) % 3];
       BnBwdArgs b;
       memset(&b, 0, sizeof(b));
-      b.g = out1; b.a = ws + P.offA; b.dz = out2; b.B = batch; b.N = P.n_out;
+      b.g = tmp; b.a = ws + P.offA; b.dz = ws + P.offDz; b.B = batch; b.N = P.n_out;
       b.part = part;
       b.n_tiles = stats_row_tiles(batch, P.n_out, L.n_out);
       b.gamma = params + P.offg; b.save_mean = ws + P.offMean;
@@ -1056,17 +1077,19 @@ int lipasr_mlp_train_fwd_bwd(lipasr_mlp_t m, const float* params, float* bnstate
       const dim3 grid((P.n_out + 127) / 128, (batch + kApplyRows - 1) / kApplyRows);
       hipLaunchKernelGGL(bn_apply_bwd_kernel, grid, apply_block, 0, st, b);
       LP_LAUNCH_CHECK();
-      gin = out2;
-      cur = (cur + 2) % 3;
-    } else {
-      gin = out1;
-      cur = (cur + 1) % 3;
     }
   }
-  // join: every weight gradient is complete before anything later on `stream` (the side stream runs its GEMMs
-  // in order, so the last event covers them all)
-  LP_HIP(hipStreamWaitEvent(st, m->ev_dw[0], 0));
-  return LIPASR_OK;
+  // [dW ; db] = [lin ; 1]^T[n_in+1][B] * gin[B][n_out] for every layer: the all-ones row yields the bias gradient
+  GemmArgs gw[LIPASR_MAX_LAYERS];
+  for (int l = 0; l < Lc; ++l) {
+    const MlpLayer& L = m->L[l];
+    const float* lin = (l == 0) ? x : (ws + m->L[l - 1].offH);
+    const float* gin = (l == Lc - 1) ? (ws + m->offDzLast) : (ws + L.offDz);
+    gw[l] = gemm_args(lin, L.n_in, gin, L.n_out, grads + L.offW, L.n_out, L.n_in + 1, L.n_out, batch, EPI_STORE);
+    gw[l].ones_row = 1;
+    gw[l].extra_out = grads + L.offb;
+  }
+  return launch_gemm_group_tn(gw, Lc, st);
 }
 
 int lipasr_mlp_predict(lipasr_mlp_t m, const float* params, const float* bnstate, const float* x, int batch,

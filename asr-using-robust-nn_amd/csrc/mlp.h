@@ -16,6 +16,7 @@ struct MlpLayer {
   size_t offA = 0;     // post-ReLU activations [max_batch][n_out]            (hidden layers)
   size_t offH = 0;     // post-BN/dropout activations = next layer's input     (== offA if neither)
   size_t offMean = 0;  // saved batch mean [n_out], rstd follows at offMean + n_out (BN layers)
+  size_t offDz = 0;    // gradient at this layer's pre-activation [max_batch][n_out] (kept for the grouped dW launch)
 };
 
 constexpr float kBnMomentum = 0.99f;  // Keras BatchNormalization defaults (train_constraints.py:68)
@@ -33,8 +34,5 @@ struct lipasr_mlp {
   float* ws = nullptr;  // workspace
   size_t ws_floats = 0;
   size_t offLogits = 0, offProb = 0, offDzLast = 0, offG0 = 0, offG1 = 0, offG2 = 0, offPart = 0;
-  // weight-gradient GEMMs run on a forked side stream, concurrently with the dX / BatchNorm-backward chain
-  hipStream_t side = nullptr;
-  hipEvent_t ev_fork[LIPASR_MAX_LAYERS] = {};
-  hipEvent_t ev_dw[LIPASR_MAX_LAYERS] = {};
+
 };
