@@ -164,32 +164,44 @@ struct OrderArgs {
 };
 
 // One workgroup: G = sum of partial Grams; sigma = sqrt(lambda_max(G)); closed-form sequential scales.
-__global__ __launch_bounds__(256) void product_sigma_kernel(const double* __restrict__ gram_part, int n_part, int R,
-                                                             double rho, OrderArgs oa, float* __restrict__ scales,
-                                                             float* __restrict__ norms_out, float* __restrict__ sigma_out) {
+constexpr int kSigmaThreads = 1024;
+constexpr int kSliceDoubles = 1024;  // LDS for the sliced partial sums: min(32, 1024 / R^2) slices x R^2 entries
+
+__global__ __launch_bounds__(kSigmaThreads) void product_sigma_kernel(const double* __restrict__ gram_part, int n_part,
+                                                                       int R, double rho, OrderArgs oa,
+                                                                       float* __restrict__ scales,
+                                                                       float* __restrict__ norms_out,
+                                                                       float* __restrict__ sigma_out) {
   __shared__ double A[kMaxR * kMaxR];
   __shared__ double B[kMaxR * kMaxR];
-  __shared__ double slice_sum[4 * kMaxR * kMaxR];
+  __shared__ double slice_sum[kSliceDoubles];
   __shared__ double tr_s;
   const int tid = threadIdx.x;
   const int RR = R * R;
-  // Gram = sum of the per-workgroup partials: entries over threads, partial index split 4 ways (fixed order)
+  // Gram = sum of the per-workgroup partials.  The partials were written by other XCDs, so every load is a trip to
+  // memory: thread (slice, entry) takes partials slice, slice + n_sl, ... with eight loads in flight, fixed order.
   {
-    for (int e = tid; e < RR * 4; e += 256) {
-      const int ent = e % RR, sl = e / RR;
-      const int p0 = (n_part * sl) / 4, p1 = (n_part * (sl + 1)) / 4;
-      double s0 = 0.0, s1 = 0.0;
-      int p = p0;
-      for (; p + 1 < p1; p += 2) {
-        s0 += gram_part[(size_t)p * RR + ent];
-        s1 += gram_part[(size_t)(p + 1) * RR + ent];
+    int n_sl = kSigmaThreads / RR;  // R <= 32, so at least one
+    if (n_sl > 32) n_sl = 32;
+    if (n_sl > n_part) n_sl = n_part;
+    const int sl = tid / RR, ent = tid - sl * RR;
+    if (sl < n_sl) {
+      double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+      for (int p = sl; p < n_part; p += 8 * n_sl) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int q = p + u * n_sl;
+          acc[u] += (q < n_part) ? gram_part[(size_t)q * RR + ent] : 0.0;
+        }
       }
-      if (p < p1) s0 += gram_part[(size_t)p * RR + ent];
-      slice_sum[sl * kMaxR * kMaxR + ent] = s0 + s1;
+      slice_sum[sl * RR + ent] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
     }
     __syncthreads();
-    for (int e = tid; e < RR; e += 256)
-      A[e] = (slice_sum[e] + slice_sum[kMaxR * kMaxR + e]) + (slice_sum[2 * kMaxR * kMaxR + e] + slice_sum[3 * kMaxR * kMaxR + e]);
+    for (int e = tid; e < RR; e += kSigmaThreads) {
+      double s = 0.0;
+      for (int k = 0; k < n_sl; ++k) s += slice_sum[k * RR + e];
+      A[e] = s;
+    }
   }
   __syncthreads();
   if (tid == 0) {
@@ -203,29 +215,29 @@ __global__ __launch_bounds__(256) void product_sigma_kernel(const double* __rest
   bool zero = !(t0 > 0.0);
   if (!zero) {
     log_lambda = log(t0);
-    for (int e = tid; e < RR; e += 256) A[e] /= t0;
+    for (int e = tid; e < RR; e += kSigmaThreads) A[e] /= t0;
     __syncthreads();
     double wgt = 0.5;
+    // A <- A^2 / tr(A^2): two barriers per squaring, every thread forms the trace itself (no serial section)
+    double* cur = A;
+    double* nxt = B;
     for (int it = 0; it < kSquarings; ++it) {
-      for (int e = tid; e < RR; e += 256) {
+      for (int e = tid; e < RR; e += kSigmaThreads) {
         const int a = e / R, b = e - a * R;
         double s = 0.0;
-        for (int c = 0; c < R; ++c) s = fma(A[a * R + c], A[c * R + b], s);
-        B[e] = s;
+        for (int c = 0; c < R; ++c) s = fma(cur[a * R + c], cur[c * R + b], s);
+        nxt[e] = s;
       }
       __syncthreads();
-      if (tid == 0) {
-        double t = 0.0;
-        for (int a = 0; a < R; ++a) t += B[a * R + a];
-        tr_s = t;
-      }
-      __syncthreads();
-      const double tj = tr_s;
+      double tj = 0.0;
+      for (int a = 0; a < R; ++a) tj += nxt[a * R + a];
       log_lambda += wgt * log(tj);
       wgt *= 0.5;
-      for (int e = tid; e < RR; e += 256) A[e] = B[e] / tj;
+      const double inv = 1.0 / tj;
+      for (int e = tid; e < RR; e += kSigmaThreads) nxt[e] *= inv;
       __syncthreads();
-      if (fabs(tj - 1.0) < 1e-15) break;  // A is a rank-1 projector: converged (uniform across threads)
+      double* t = cur; cur = nxt; nxt = t;
+      if (fabs(tj - 1.0) < 1e-15) break;  // rank-1 projector reached: converged (same value in every thread)
     }
   }
   if (tid == 0) {
@@ -606,6 +618,185 @@ static int run_power_iteration(lipasr_ctx* h, PiArgs& a, int warm, int iters, hi
   return LIPASR_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Singular-value clipping of an R x n matrix, R <= 32 (norm_constraint_FISTA, Constraints.py:78-91).
+// X = U S V^T  =>  U min(S, hi) V^T = M X  with  M = U diag(min(s, hi) / s) U^T, and U, S^2 are the
+// eigen-pairs of the R x R Gram matrix X X^T.  One workgroup: Gram in fp64 through an LDS tile,
+// cyclic Jacobi with the round-robin (tournament) ordering so that R/2 disjoint rotations run at
+// once, then M X column by column.  Fixed summation order; no atomics.
+// ---------------------------------------------------------------------------------------------
+constexpr int kSvTile = 256;
+constexpr int kSvLd = kMaxR + 1;
+constexpr int kSvMaxSweeps = 30;
+
+__global__ __launch_bounds__(256) void sv_clip_kernel(const float* __restrict__ X, int R, int n, double hi,
+                                                       float* out, float* __restrict__ svals_out) {
+  __shared__ double G[kMaxR * kSvLd];
+  __shared__ double V[kMaxR * kSvLd];
+  __shared__ double cs[kMaxR];  // (c, s) per pair
+  __shared__ int pq[kMaxR];     // (p, q) per pair, p < q; -1 when the pair holds the bye
+  __shared__ double red[kMaxR + 1];
+  __shared__ float tile[kMaxR * (kSvTile + 1)];
+  const int tid = threadIdx.x;
+  const int RR = R * R;
+  // ---- Gram
+  double acc[(kMaxR * kMaxR) / 256] = {0.0, 0.0, 0.0, 0.0};
+  for (int j0 = 0; j0 < n; j0 += kSvTile) {
+    __syncthreads();
+    for (int r = 0; r < R; ++r) tile[r * (kSvTile + 1) + tid] = (j0 + tid < n) ? X[(size_t)r * n + j0 + tid] : 0.0f;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < (kMaxR * kMaxR) / 256; ++u) {
+      const int e = tid + 256 * u;
+      if (e < RR) {
+        const int a = e / R, b = e - a * R;
+        const float* ta = tile + a * (kSvTile + 1);
+        const float* tb = tile + b * (kSvTile + 1);
+        double s = 0.0;
+        for (int c = 0; c < kSvTile; ++c) s = fma((double)ta[c], (double)tb[c], s);
+        acc[u] += s;
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < (kMaxR * kMaxR) / 256; ++u) {
+    const int e = tid + 256 * u;
+    if (e < RR) {
+      const int a = e / R, b = e - a * R;
+      G[a * kSvLd + b] = acc[u];
+      V[a * kSvLd + b] = (a == b) ? 1.0 : 0.0;
+    }
+  }
+  __syncthreads();
+  // ---- Jacobi: G <- J^T G J, V <- V J
+  const int Re = (R + 1) & ~1;  // players in the tournament (one bye when R is odd)
+  const int n_pairs = Re / 2;
+  for (int sweep = 0; sweep < kSvMaxSweeps; ++sweep) {
+    // convergence: sum of squared off-diagonal entries against the squared diagonal
+    if (tid < R) {
+      double o = 0.0;
+      for (int j = 0; j < R; ++j)
+        if (j != tid) o = fma(G[tid * kSvLd + j], G[tid * kSvLd + j], o);
+      red[tid] = o;
+    }
+    __syncthreads();
+    double off = 0.0, dg = 0.0;
+    for (int i = 0; i < R; ++i) {
+      off += red[i];
+      dg = fma(G[i * kSvLd + i], G[i * kSvLd + i], dg);
+    }
+    __syncthreads();
+    if (!(off > 1e-30 * dg)) break;  // identical in every thread
+    for (int round = 0; round < Re - 1; ++round) {
+      if (tid < n_pairs) {
+        int p, q;
+        if (tid == 0) {
+          p = Re - 1;
+          q = round;
+        } else {
+          p = (round + tid) % (Re - 1);
+          q = (round - tid + (Re - 1)) % (Re - 1);
+        }
+        if (p > q) { const int t = p; p = q; q = t; }
+        double c = 1.0, sn = 0.0;
+        if (q >= R) {
+          p = -1;
+        } else {
+          const double gpp = G[p * kSvLd + p], gqq = G[q * kSvLd + q], gpq = G[p * kSvLd + q];
+          if (fabs(gpq) > 1e-300 && fabs(gpq) > 1e-18 * sqrt(fabs(gpp * gqq))) {
+            const double tau = (gqq - gpp) / (2.0 * gpq);
+            const double t = ((tau >= 0.0) ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+            c = 1.0 / sqrt(1.0 + t * t);
+            sn = t * c;
+          }
+        }
+        pq[2 * tid] = p;
+        pq[2 * tid + 1] = q;
+        cs[2 * tid] = c;
+        cs[2 * tid + 1] = sn;
+      }
+      __syncthreads();
+      // columns p, q of G and of V
+      for (int e = tid; e < n_pairs * R; e += 256) {
+        const int k = e / R, i = e - k * R;
+        const int p = pq[2 * k], q = pq[2 * k + 1];
+        if (p < 0) continue;
+        const double c = cs[2 * k], sn = cs[2 * k + 1];
+        const double gip = G[i * kSvLd + p], giq = G[i * kSvLd + q];
+        G[i * kSvLd + p] = c * gip - sn * giq;
+        G[i * kSvLd + q] = sn * gip + c * giq;
+        const double vip = V[i * kSvLd + p], viq = V[i * kSvLd + q];
+        V[i * kSvLd + p] = c * vip - sn * viq;
+        V[i * kSvLd + q] = sn * vip + c * viq;
+      }
+      __syncthreads();
+      // rows p, q of G
+      for (int e = tid; e < n_pairs * R; e += 256) {
+        const int k = e / R, j = e - k * R;
+        const int p = pq[2 * k], q = pq[2 * k + 1];
+        if (p < 0) continue;
+        const double c = cs[2 * k], sn = cs[2 * k + 1];
+        const double gpj = G[p * kSvLd + j], gqj = G[q * kSvLd + j];
+        G[p * kSvLd + j] = c * gpj - sn * gqj;
+        G[q * kSvLd + j] = sn * gpj + c * gqj;
+      }
+      __syncthreads();
+    }
+  }
+  // ---- singular values (descending) and the clipping factors
+  if (tid < R) {
+    const double lam = G[tid * kSvLd + tid];
+    const double sv = (lam > 0.0) ? sqrt(lam) : 0.0;
+    red[tid] = sv;
+    cs[tid] = (sv > hi) ? hi / sv : 1.0;
+  }
+  __syncthreads();
+  if (svals_out && tid < R) {
+    const double mine = red[tid];
+    int rank = 0;
+    for (int k = 0; k < R; ++k) rank += (red[k] > mine || (red[k] == mine && k < tid)) ? 1 : 0;
+    svals_out[rank] = (float)mine;
+  }
+  if (!out) return;
+  // M = V diag(f) V^T, kept in G
+  double mloc[(kMaxR * kMaxR) / 256];
+#pragma unroll
+  for (int u = 0; u < (kMaxR * kMaxR) / 256; ++u) {
+    const int e = tid + 256 * u;
+    mloc[u] = 0.0;
+    if (e < RR) {
+      const int a = e / R, b = e - a * R;
+      double s = 0.0;
+      for (int k = 0; k < R; ++k) s = fma(cs[k] * V[a * kSvLd + k], V[b * kSvLd + k], s);
+      mloc[u] = s;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < (kMaxR * kMaxR) / 256; ++u) {
+    const int e = tid + 256 * u;
+    if (e < RR) G[(e / R) * kSvLd + (e % R)] = mloc[u];
+  }
+  __syncthreads();
+  // ---- out = M X, one column per thread (in place allowed: a tile is read before it is written)
+  for (int j0 = 0; j0 < n; j0 += kSvTile) {
+    const int j = j0 + tid;
+    if (j < n) {
+      float xcol[kMaxR];
+#pragma unroll
+      for (int b = 0; b < kMaxR; ++b) xcol[b] = (b < R) ? X[(size_t)b * n + j] : 0.0f;
+      for (int a = 0; a < R; ++a) {
+        double s = 0.0;
+#pragma unroll
+        for (int b = 0; b < kMaxR; ++b)
+          if (b < R) s = fma(G[a * kSvLd + b], (double)xcol[b], s);
+        out[(size_t)a * n + j] = (float)s;
+      }
+    }
+  }
+}
+
 }  // namespace lipasr
 
 using namespace lipasr;
@@ -666,7 +857,7 @@ int lipasr_project_product(lipasr_handle_t h, float* const* Ws, const int* rows,
   int n_part = 0;
   rc = launch_chain(h, Ws, rows, cols, n_layers, &cs, &n_part, S(stream));
   if (rc != LIPASR_OK) return rc;
-  hipLaunchKernelGGL(product_sigma_kernel, dim3(1), dim3(256), 0, S(stream), cs.gram, n_part, cols[n_layers - 1],
+  hipLaunchKernelGGL(product_sigma_kernel, dim3(1), dim3(kSigmaThreads), 0, S(stream), cs.gram, n_part, cols[n_layers - 1],
                      (double)rho, oa, cs.scales, norms_out, cs.sigma);
   LP_LAUNCH_CHECK();
   if (n_order > 0) {
@@ -691,7 +882,7 @@ int lipasr_product_norm(lipasr_handle_t h, const float* const* Ws, const int* ro
   OrderArgs oa;
   oa.n_layers = n_layers;
   oa.n_order = 0;
-  hipLaunchKernelGGL(product_sigma_kernel, dim3(1), dim3(256), 0, S(stream), cs.gram, n_part, cols[n_layers - 1], 1.0,
+  hipLaunchKernelGGL(product_sigma_kernel, dim3(1), dim3(kSigmaThreads), 0, S(stream), cs.gram, n_part, cols[n_layers - 1], 1.0,
                      oa, (float*)nullptr, (float*)nullptr, sigma_out);
   LP_LAUNCH_CHECK();
   return LIPASR_OK;
@@ -712,6 +903,17 @@ int lipasr_bn_correction(lipasr_handle_t h, const float* gamma, const float* var
                          lipasr_stream_t stream) {
   LP_CHECK_ARG(h && gamma && var && out && n > 0, "lipasr_bn_correction: bad argument");
   hipLaunchKernelGGL(bn_correction_kernel, dim3(1), dim3(256), 0, S(stream), gamma, var, n, out);
+  LP_LAUNCH_CHECK();
+  return LIPASR_OK;
+}
+
+int lipasr_sv_clip(lipasr_handle_t h, const float* X, int R, int n, float hi, float* out, float* svals_out,
+                   lipasr_stream_t stream) {
+  LP_CHECK_ARG(h && X, "lipasr_sv_clip: null argument");
+  LP_CHECK_ARG(out || svals_out, "lipasr_sv_clip: nothing to compute (out and svals_out both null)");
+  LP_CHECK_ARG(R >= 1 && R <= kMaxR && n >= 1, "lipasr_sv_clip: needs 1 <= R <= 32 rows and n >= 1 columns");
+  LP_CHECK_ARG(hi >= 0.0f, "lipasr_sv_clip: negative clipping level");
+  hipLaunchKernelGGL(sv_clip_kernel, dim3(1), dim3(256), 0, S(stream), X, R, n, (double)hi, out, svals_out);
   LP_LAUNCH_CHECK();
   return LIPASR_OK;
 }

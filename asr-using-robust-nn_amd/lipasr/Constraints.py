@@ -183,9 +183,10 @@ class simple_norm_constraint(Callback):
 class norm_constraint_FISTA(Callback):
     """Constraints.py:54-130: dual forward-backward projection with singular-value clipping.
 
-    Surface row: the products run on the device through lipasr_gemm_f32; the two
-    small SVDs per iteration (10 x in_i and n_out x n_in) use the GPU LAPACK behind torch.linalg.svd --
-    a hand-written batched small-SVD kernel is the 'next' row."""
+    Every step runs on the device: the products through lipasr_gemm_f32 (fp32 MFMA), the thin SVDs of the
+    (classes x n_0) iterates and their clipping through lipasr_sv_clip (Gram + Jacobi in fp64), the step size
+    from the spectral norms of A (lipasr_sv_clip) and B (lipasr_sigma_max).  Two scalars per iteration come
+    back to the host for the reference's early-exit test (:91)."""
 
     def __init__(self, rho, nit):
         super().__init__()
@@ -206,13 +207,37 @@ class norm_constraint_FISTA(Callback):
                                       N.ptr(out), b.shape[1], N.stream_ptr()))
         return out
 
+    @staticmethod
+    def _sv_clip(x, hi=None, want_out=True):
+        """(U min(S, hi) V^T, S) of a (R <= 32) x n device matrix; ``hi=None`` leaves S alone."""
+        x = x.contiguous()
+        h = N.get_handle(x.device.index)
+        out = torch.empty_like(x) if want_out else None
+        sv = torch.empty(x.shape[0], device=x.device)
+        N.check(N.lib.lipasr_sv_clip(h.h, N.ptr(x), x.shape[0], x.shape[1], float("inf") if hi is None else float(hi),
+                                     N.ptr(out) if want_out else None, N.ptr(sv), N.stream_ptr()))
+        return out, sv
+
+    @classmethod
+    def _norm2(cls, a, iters=300):
+        """np.linalg.norm(a, ord=2) (Constraints.py:72) on the device."""
+        if a.shape[0] == a.shape[1] and getattr(a, "_lipasr_identity", False):
+            return 1.0
+        if min(a.shape) <= 32:
+            x = a if a.shape[0] <= 32 else a.t()
+            return float(cls._sv_clip(x, want_out=False)[1][0])
+        a = a.contiguous()
+        h = N.get_handle(a.device.index)
+        v = torch.empty(a.shape[1], device=a.device)
+        out = torch.empty(1, device=a.device)
+        N.check(N.lib.lipasr_sigma_max(h.h, N.ptr(a), a.shape[0], a.shape[1], N.ptr(v), 0, iters, 0, N.ptr(out), N.stream_ptr()))
+        return float(out)
+
     def Constraint_Fista(self, w, Y0, A, B, nit, rho):
         """Constraints.py:69-94 on device tensors; ``w`` is the transposed kernel (out, in)."""
         mm = self._mm
         Y, Yold = Y0, Y0
-        sa = torch.linalg.matrix_norm(A.double(), ord=2)
-        sb = torch.linalg.matrix_norm(B.double(), ord=2)
-        gam = float(1.0 / ((sa * sb + np.spacing(1)) ** 2))
+        gam = float(1.0 / ((self._norm2(A) * self._norm2(B) + np.spacing(1)) ** 2))
         alpha = 2.1
         w_new = w
         for i in range(nit):
@@ -222,14 +247,12 @@ class norm_constraint_FISTA(Callback):
             w_new = w - mm(mm(A.t(), Z), B.t())
             w_new = w_new * (w_new >= 0)
             T = mm(mm(A, w_new), B)
-            s = torch.linalg.svdvals(T.double())
+            s = self._sv_clip(T, want_out=False)[1]  # :78-79 singular values of T
             criterion = float(torch.linalg.norm(w_new - w))
-            over = s[s > rho] - rho
-            constraint = float(torch.linalg.norm(over)) if over.numel() else 0.0
+            constraint = float(torch.linalg.norm(torch.clamp(s - rho, min=0.0)))  # :81 ||s[s > rho] - rho||_2
             Yt = Z + gam * T
-            u1, s1, v1 = torch.linalg.svd((Yt / gam).double(), full_matrices=False)
-            s1 = torch.clamp(s1, 0, rho)
-            Y = Yt - gam * ((u1 * s1) @ v1).float()
+            # :86-89  Yt - gam * U clip(S / gam, 0, rho) V^T  ==  Yt - U min(S, rho * gam) V^T  with U S V^T = svd(Yt)
+            Y = Yt - self._sv_clip(Yt, hi=rho * gam)[0]
             if criterion < 30 and constraint < 0.01:
                 return w_new
         return w_new
@@ -256,8 +279,10 @@ class norm_constraint_FISTA(Callback):
                 B = ws[index].t().contiguous() if B is None else self._mm(B, ws[index].t())
         if w_index == 0:
             B = torch.eye(wk.shape[0], device=dev)
+            B._lipasr_identity = True
         if w_index == len(ws) - 1:
             A = torch.eye(wk.shape[1], device=dev)
+            A._lipasr_identity = True
         Y0 = torch.zeros(A.shape[0], B.shape[1], device=dev)
         return self.Constraint_Fista(wk.t().contiguous(), Y0, A, B, self.nit, self.rho)
 

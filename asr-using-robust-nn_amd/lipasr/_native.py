@@ -15,7 +15,8 @@ import os
 import torch  # noqa: F401  (plumbing: device memory, streams, process groups)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblipasr.so")
+# LIPASR_LIBRARY: another build of the same library (A/B timing of kernel changes); never a different backend
+LIB_PATH = os.environ.get("LIPASR_LIBRARY") or os.path.join(_HERE, "liblipasr.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -64,6 +65,7 @@ PROTOTYPES = {
     "lipasr_product_norm": (i32, [c_h, PV, PI, PI, i32, c_f, c_s]),
     "lipasr_frobenius_project": (i32, [c_h, c_f, sz, f32, c_s]),
     "lipasr_bn_correction": (i32, [c_h, c_f, c_f, i32, c_f, c_s]),
+    "lipasr_sv_clip": (i32, [c_h, c_f, i32, i32, f32, c_f, c_f, c_s]),
     "lipasr_sign_step": (i32, [c_h, c_f, c_f, c_f, sz, f32, f32, c_s]),
     "lipasr_scaler_fit": (i32, [c_h, c_f, i32, i32, c_f, c_f, c_s]),
     "lipasr_scaler_apply": (i32, [c_h, c_f, i32, i32, c_f, c_f, c_f, c_s]),

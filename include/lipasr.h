@@ -115,6 +115,14 @@ int lipasr_frobenius_project(lipasr_handle_t h, float* W, size_t n, float rho, l
 int lipasr_bn_correction(lipasr_handle_t h, const float* gamma, const float* var, int n, float* out,
                          lipasr_stream_t stream);
 
+/* norm_constraint_FISTA's singular-value steps (Constraints.py:78-79 `svd(T)` for the constraint
+ * read-out, :86-88 `svd(Yt / gam, full_matrices=False); clip(s1, 0, rho); dot(u1 * s1, v1)`):
+ * X is device [R][n] row-major with R <= 32 (the class dimension).  out (device [R][n], may alias
+ * X, may be NULL) receives U min(S, hi) V^T; svals_out (device [R], may be NULL) the singular
+ * values in descending order.  Thin SVD through the fp64 Gram matrix X X^T (Jacobi). */
+int lipasr_sv_clip(lipasr_handle_t h, const float* X, int R, int n, float hi, float* out, float* svals_out,
+                   lipasr_stream_t stream);
+
 /* ------------------------------------------------------------------ K4: sign step
  * ART FastGradientMethod / ProjectedGradientDescent update (attacks.py:506-510, 657-661),
  * norm=inf, no clip_values: x_adv <- x0 + clip(x_adv + alpha*sign(g) - x0, -eps, +eps), in place.

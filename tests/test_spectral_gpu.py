@@ -154,6 +154,31 @@ def test_custom_constraint_frobenius(cuda):
     out = c(t)
     assert out.is_cuda and out.data_ptr() != t.data_ptr() and torch.equal(t.cpu(), torch.as_tensor(w))  # pure function
 
+@pytest.mark.parametrize("R_,n,hi", [(10, 880, 3.0), (6, 24, 0.5), (32, 1000, 20.0), (1, 5, 0.1), (7, 3, 0.4), (10, 880, 0.0)])
+def test_sv_clip_matches_lapack(cuda, R_, n, hi):
+    """lipasr_sv_clip against numpy's SVD (Constraints.py:86-89 arithmetic) on seeded matrices."""
+    import lipasr._native as N
+
+    rng = np.random.default_rng(100 + R_ + n)
+    x = rng.standard_normal((R_, n)).astype(np.float32)
+    x[0] *= 4.0  # spread the spectrum so that some values are clipped and some are not
+    u, sv, vt = np.linalg.svd(x.astype(np.float64), full_matrices=False)
+    want = (u * np.clip(sv, 0, hi)) @ vt
+    xt = torch.as_tensor(x).cuda()
+    out = torch.empty_like(xt)
+    got_sv = torch.empty(R_, device="cuda")
+    h = N.get_handle(0)
+    N.check(N.lib.lipasr_sv_clip(h.h, N.ptr(xt), R_, n, hi, N.ptr(out), N.ptr(got_sv), N.stream_ptr()))
+    k = min(R_, n)
+    np.testing.assert_allclose(got_sv.cpu().numpy()[:k], sv[:k], rtol=2e-6, atol=1e-6 * sv[0])
+    assert np.all(np.abs(got_sv.cpu().numpy()[k:]) <= 1e-6 * sv[0])
+    assert np.max(np.abs(out.cpu().numpy() - want)) <= 2e-6 * max(sv[0], 1.0)
+    # in place, singular values only, and argument checking
+    N.check(N.lib.lipasr_sv_clip(h.h, N.ptr(xt), R_, n, hi, N.ptr(xt), None, N.stream_ptr()))
+    assert torch.equal(xt, out)
+    assert N.lib.lipasr_sv_clip(h.h, N.ptr(xt), 33, n, hi, N.ptr(xt), None, N.stream_ptr()) == N.EINVAL
+    assert N.lib.lipasr_sv_clip(h.h, N.ptr(xt), R_, n, hi, None, None, N.stream_ptr()) == N.EINVAL
+
 
 def test_fista_surface(cuda):
     from lipasr.Constraints import norm_constraint_FISTA
