@@ -25,6 +25,11 @@ struct MfccPlan {
   int sr_in = 0, n_samp = 0, batch_max = 0;
   int up = 1, down = 1, taps = 0, left = 0;
   int n_valid = 0, n_y = 0, n_frames = 0;
+  int n_fft = kNFft, hop = kHop;
+  bool dft = false;          // short-window variant: STFT as an MFMA contraction (dft_mel_kernel)
+  int dft_krows = 0, dft_tiles = 0, dft_rpc = 0;
+  float* d_dft = nullptr;    // [dft_krows][dft_tiles*64] windowed DFT matrix
+  float* d_ypad = nullptr;   // reflect-padded clips, dft_rpc*hop floats each (+ a zero tail)
   bool identity = false;  // sr_in == 22050
   float* d_h = nullptr;   // [up][taps]
   int* d_noff = nullptr;  // [up]
@@ -54,7 +59,7 @@ struct MfccPlan {
 
 void mfcc_plan_free(MfccPlan* p) {
   if (!p) return;
-  void* ptrs[] = {p->d_twB, p->d_mel_wlo, p->d_mel_whi, p->d_mel_pstart, p->d_mel_plen, p->d_hband, p->d_lo, p->d_h, p->d_noff, p->d_hann, p->d_tw, p->d_mel_start, p->d_mel_len, p->d_mel_off,
+  void* ptrs[] = {p->d_dft, p->d_ypad, p->d_twB, p->d_mel_wlo, p->d_mel_whi, p->d_mel_pstart, p->d_mel_plen, p->d_hband, p->d_lo, p->d_h, p->d_noff, p->d_hann, p->d_tw, p->d_mel_start, p->d_mel_len, p->d_mel_off,
                   p->d_mel_w, p->d_dct, p->d_y, p->d_db, p->d_fmax};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
@@ -642,8 +647,130 @@ __global__ __launch_bounds__(256) void stft_mel_wave_kernel(StftArgs a, const fl
 }
 
 // ---------------------------------------------------------------------------------------------
+// stage 2 for a short window of any length (Speaker recognition/extract_features_construct_dataset.py:224-226:
+// librosa.feature.mfcc(win_length=441, n_fft=441, hop_length=220), 1 + 22050/220 = 101 frames): the windowed
+// real DFT evaluated as an fp32 MFMA contraction  frames[rows][n_fft] x table[n_fft][re | im].
+//
+// Layout: every clip is reflect-padded into rpc*hop floats (rpc = rows per clip, so that global frame row r
+// starts at ypad + r*hop for ALL clips: the overlapping frames are just a matrix with leading dimension hop;
+// rows frame >= n_frames of a clip are computed and dropped).  One workgroup takes 64 consecutive rows: their
+// samples (63*hop + K floats) are staged in LDS once, wavefront t owns the 32 bins of tile t and streams the
+// table's 64 columns (re, im) for those bins from L2 in double-buffered groups of 8 K-steps, four
+// 32x32x2 MFMA accumulators (2 row blocks x re/im).  Power goes back to LDS, then mel (CSR bank, sequential
+// fp32 like the FFT path), dB and the per-frame maximum, one wavefront per row.
+// ---------------------------------------------------------------------------------------------
+struct DftArgs {
+  const float* ypad;
+  const float* table;  // [k_rows][n_tiles*64]
+  int hop, k_rows, n_tiles, rpc, n_frames, total_rows;
+  const int* mel_start;
+  const int* mel_len;
+  const int* mel_off;
+  const float* mel_w;
+  float* db;    // [B][n_frames][128]
+  float* fmax;  // [B][n_frames]
+};
+constexpr int kDftRows = 64, kDftGroup = 8, kDftMaxTiles = 8;
+
+__global__ __launch_bounds__(256) void reflect_pad_kernel(const float* __restrict__ y, int n_y, int pad,
+                                                           float* __restrict__ ypad, int stride) {
+  const int u = blockIdx.y;
+  for (int j = blockIdx.x * 256 + threadIdx.x; j < stride; j += gridDim.x * 256) {
+    float v = 0.0f;
+    if (j < n_y + 2 * pad) {
+      int i = j - pad;  // np.pad(mode='reflect'): the edge sample is not repeated
+      if (i < 0) i = -i;
+      else if (i >= n_y) i = 2 * (n_y - 1) - i;
+      v = y[(size_t)u * n_y + i];
+    }
+    ypad[(size_t)u * stride + j] = v;
+  }
+}
+
+__global__ __launch_bounds__(64 * kDftMaxTiles) void dft_mel_kernel(DftArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float dsm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x, n_waves = nthreads >> 6;
+  const int row0 = blockIdx.x * kDftRows;
+  {
+    const float* src = a.ypad + (size_t)row0 * a.hop;
+    const int n_a = (kDftRows - 1) * a.hop + a.k_rows;
+    for (int i = tid; i < n_a; i += nthreads) dsm[i] = src[i];
+  }
+  __syncthreads();
+  const int li = lane & 31, kk = lane >> 5;
+  const int ld = a.n_tiles * 64;
+  rs_f32x16 re0, im0, re1, im1;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) { re0[q] = 0.f; im0[q] = 0.f; re1[q] = 0.f; im1[q] = 0.f; }
+  const float* bp = a.table + (size_t)kk * ld + wave * 64 + li;
+  const float* ap0 = dsm + li * a.hop + kk;
+  const float* ap1 = ap0 + 32 * a.hop;
+  const int n_groups = a.k_rows / (2 * kDftGroup);
+  float br0[kDftGroup], bi0[kDftGroup], br1[kDftGroup], bi1[kDftGroup];
+#define LP_DFT_LOAD(BR, BI, G)                                          \
+  _Pragma("unroll") for (int u = 0; u < kDftGroup; ++u) {               \
+    const float* q_ = bp + (size_t)(2 * ((G) * kDftGroup + u)) * ld;    \
+    BR[u] = q_[0];                                                      \
+    BI[u] = q_[32];                                                     \
+  }
+#define LP_DFT_MAC(BR, BI, G)                                           \
+  _Pragma("unroll") for (int u = 0; u < kDftGroup; ++u) {               \
+    const int k0_ = 2 * ((G) * kDftGroup + u);                          \
+    const float a0_ = ap0[k0_], a1_ = ap1[k0_];                         \
+    re0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0_, BR[u], re0, 0, 0, 0); \
+    im0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0_, BI[u], im0, 0, 0, 0); \
+    re1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_, BR[u], re1, 0, 0, 0); \
+    im1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_, BI[u], im1, 0, 0, 0); \
+  }
+  LP_DFT_LOAD(br0, bi0, 0)
+  for (int g = 0; g < n_groups; g += 2) {
+    if (g + 1 < n_groups) { LP_DFT_LOAD(br1, bi1, g + 1) }
+    LP_DFT_MAC(br0, bi0, g)
+    if (g + 1 < n_groups) {
+      if (g + 2 < n_groups) { LP_DFT_LOAD(br0, bi0, g + 2) }
+      LP_DFT_MAC(br1, bi1, g + 1)
+    }
+  }
+#undef LP_DFT_LOAD
+#undef LP_DFT_MAC
+  __syncthreads();  // every wavefront is done with the staged samples: the buffer becomes the power tile
+  const int ldp = a.n_tiles * 32 + 1;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int r = (q & 3) + 8 * (q >> 2) + 4 * kk;
+    dsm[r * ldp + wave * 32 + li] = re0[q] * re0[q] + im0[q] * im0[q];
+    dsm[(32 + r) * ldp + wave * 32 + li] = re1[q] * re1[q] + im1[q] * im1[q];
+  }
+  __syncthreads();
+  // mel + dB, one wavefront per frame row: lane handles filters lane and lane + 64
+  for (int r = wave; r < kDftRows; r += n_waves) {
+    const int grow = row0 + r;
+    const int clip = grow / a.rpc, frame = grow - clip * a.rpc;
+    if (grow >= a.total_rows || frame >= a.n_frames) continue;  // wave-uniform
+    const float* pr = dsm + r * ldp;
+    float dbv[2];
+#pragma unroll
+    for (int hmel = 0; hmel < 2; ++hmel) {
+      const int m = lane + 64 * hmel;
+      const int st = a.mel_start[m], ln = a.mel_len[m];
+      const float* w = a.mel_w + a.mel_off[m];
+      float sacc = 0.0f;
+      for (int j = 0; j < ln; ++j) sacc = fmaf(w[j], pr[st + j], sacc);
+      dbv[hmel] = 10.0f * log10f(fmaxf(1e-10f, sacc));  // librosa.power_to_db(ref=1, amin=1e-10)
+    }
+    float* dst = a.db + ((size_t)clip * a.n_frames + frame) * 128;
+    dst[lane] = dbv[0];
+    dst[lane + 64] = dbv[1];
+    const float mx = wave_max(fmaxf(dbv[0], dbv[1]));
+    if (lane == 0) a.fmax[(size_t)clip * a.n_frames + frame] = mx;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // stage 3: top_db floor, DCT, layout
 // ---------------------------------------------------------------------------------------------
+constexpr int kDctFrames = 64;  // frames per workgroup (blockIdx.y = chunk): LDS stays 43 KB whatever the clip length
+
 __global__ __launch_bounds__(256) void dct_kernel(const float* __restrict__ db, const float* __restrict__ frame_max,
                                                    int n_frames, int L, const float* __restrict__ dct,
                                                    const double* __restrict__ aff_mean,
@@ -651,12 +778,14 @@ __global__ __launch_bounds__(256) void dct_kernel(const float* __restrict__ db, 
   extern __shared__ __attribute__((aligned(16))) float sm[];
   __shared__ float red[4];
   const int tid = threadIdx.x, u = blockIdx.x;
-  const int tu = n_frames < L ? n_frames : L;  // frames that reach the output
-  const int tp = tu | 1;                       // odd row stride: conflict-free transposed store
-  float* dbs = sm;                             // [128][tp]
-  float* ds = sm + 128 * tp;                   // [20][128]
+  const int t0 = blockIdx.y * kDctFrames;             // first output frame of this chunk
+  const int tl = min(kDctFrames, L - t0);             // output frames of this chunk (incl. zero padding)
+  const int tu = max(0, min(n_frames - t0, tl));      // of which computed from the spectrogram
+  const int tp = kDctFrames | 1;                      // odd row stride: conflict-free transposed store
+  float* dbs = sm;                                    // [128][tp]
+  float* ds = sm + 128 * tp;                          // [20][128]
   float mx = -INFINITY;
-  for (int t = tid; t < n_frames; t += 256) mx = fmaxf(mx, frame_max[(size_t)u * n_frames + t]);
+  for (int t = tid; t < n_frames; t += 256) mx = fmaxf(mx, frame_max[(size_t)u * n_frames + t]);  // whole clip
   mx = wave_max(mx);
   if ((tid & 63) == 0) red[tid >> 6] = mx;
   for (int i = tid; i < kNMfcc * 128; i += 256) ds[i] = dct[i];
@@ -664,20 +793,21 @@ __global__ __launch_bounds__(256) void dct_kernel(const float* __restrict__ db, 
   const float thr = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) - 80.0f;  // top_db = 80
   for (int i = tid; i < tu * 128; i += 256) {
     const int t = i >> 7, m = i & 127;
-    dbs[m * tp + t] = fmaxf(db[((size_t)u * n_frames + t) * 128 + m], thr);
+    dbs[m * tp + t] = fmaxf(db[((size_t)u * n_frames + t0 + t) * 128 + m], thr);
   }
   __syncthreads();
   const int n_out = kNMfcc * L;
-  for (int o = tid; o < n_out; o += 256) {
-    const int c = o / L, t = o - c * L;
+  for (int o = tid; o < kNMfcc * tl; o += 256) {
+    const int c = o / tl, t = o - c * tl;
     float v = 0.0f;
     if (t < tu) {
       const float* dr = ds + c * 128;
 #pragma unroll 8
       for (int m = 0; m < 128; ++m) v = fmaf(dr[m], dbs[m * tp + t], v);
     }
-    if (aff_mean) v = (float)(((double)v - aff_mean[o]) / aff_scale[o]);
-    out[(size_t)u * n_out + o] = v;
+    const int oo = c * L + t0 + t;
+    if (aff_mean) v = (float)(((double)v - aff_mean[oo]) / aff_scale[oo]);
+    out[(size_t)u * n_out + oo] = v;
   }
 }
 
@@ -798,7 +928,23 @@ static int launch_from_22k(const MfccPlan* p, const float* y, int batch, int L, 
   a.mel_wlo = p->d_mel_wlo; a.mel_whi = p->d_mel_whi; a.mel_start = p->d_mel_pstart; a.mel_len = p->d_mel_plen;
   a.db = p->d_db; a.fmax = p->d_fmax;
   a.stage_mask = p->stage_mask;
-  if (!(p->stage_mask & 32)) {
+  if (p->dft) {
+    const int stride = p->dft_rpc * p->hop;
+    hipLaunchKernelGGL(reflect_pad_kernel, dim3((stride + 1023) / 1024, batch), dim3(256), 0, st, y, p->n_y, p->n_fft / 2,
+                       p->d_ypad, stride);
+    LP_LAUNCH_CHECK();
+    DftArgs d;
+    d.ypad = p->d_ypad; d.table = p->d_dft; d.hop = p->hop; d.k_rows = p->dft_krows; d.n_tiles = p->dft_tiles;
+    d.rpc = p->dft_rpc; d.n_frames = p->n_frames; d.total_rows = batch * p->dft_rpc;
+    d.mel_start = p->d_mel_start; d.mel_len = p->d_mel_len; d.mel_off = p->d_mel_off; d.mel_w = p->d_mel_w;
+    d.db = p->d_db; d.fmax = p->d_fmax;
+    const int n_a = (kDftRows - 1) * p->hop + p->dft_krows, n_p = kDftRows * (p->dft_tiles * 32 + 1);
+    const size_t dl = (size_t)(n_a > n_p ? n_a : n_p) * sizeof(float);
+    if (dl > 48 * 1024)
+      LP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dft_mel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)dl));
+    hipLaunchKernelGGL(dft_mel_kernel, dim3((d.total_rows + kDftRows - 1) / kDftRows), dim3(64 * p->dft_tiles), dl, st, d);
+  } else if (!(p->stage_mask & 32)) {
     hipLaunchKernelGGL(stft_mel_kernel, dim3((p->n_frames + 1) / 2, batch), dim3(256), 0, st, a);
   } else {
     const size_t wl = (size_t)4 * kWvBuf * sizeof(float2);
@@ -814,17 +960,9 @@ static int launch_from_22k(const MfccPlan* p, const float* y, int batch, int L, 
   }
   LP_LAUNCH_CHECK();
   if (mid) LP_HIP(hipEventRecord(mid, st));
-  const int tu = p->n_frames < L ? p->n_frames : L;
-  const size_t lds = ((size_t)128 * (tu | 1) + kNMfcc * 128) * sizeof(float);
-  if (lds > 150 * 1024) {
-    set_error("mfcc: utterance_length %d needs %zu bytes of LDS", L, lds);
-    return LIPASR_EUNSUPPORTED;
-  }
-  if (lds > 48 * 1024)
-    LP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dct_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)lds));
-  hipLaunchKernelGGL(dct_kernel, dim3(batch), dim3(256), lds, st, p->d_db, p->d_fmax, p->n_frames, L, p->d_dct, am, as,
-                     out);
+  const size_t lds = ((size_t)128 * (kDctFrames | 1) + kNMfcc * 128) * sizeof(float);
+  hipLaunchKernelGGL(dct_kernel, dim3(batch, (L + kDctFrames - 1) / kDctFrames), dim3(256), lds, st, p->d_db, p->d_fmax,
+                     p->n_frames, L, p->d_dct, am, as, out);
   LP_LAUNCH_CHECK();
   return LIPASR_OK;
 }
@@ -836,7 +974,17 @@ using namespace lipasr;
 extern "C" {
 
 int lipasr_mfcc_plan(lipasr_handle_t h, int sr_in, int n_samp, int batch_max) {
+  return lipasr_mfcc_plan_ex(h, sr_in, n_samp, batch_max, kNFft, kHop);
+}
+
+int lipasr_mfcc_plan_ex(lipasr_handle_t h, int sr_in, int n_samp, int batch_max, int n_fft, int hop) {
   LP_CHECK_ARG(h != nullptr, "lipasr_mfcc_plan: null handle");
+  const bool dft = !(n_fft == kNFft && hop == kHop);
+  if (dft && !(n_fft >= 32 && n_fft <= 32 * kDftMaxTiles * 2 - 2 && hop >= 1 && hop <= n_fft)) {
+    set_error("lipasr_mfcc_plan_ex: n_fft=%d hop=%d; supported: 2048/512 (FFT path) or 32 <= n_fft <= %d with "
+              "1 <= hop <= n_fft (DFT-contraction path)", n_fft, hop, 32 * kDftMaxTiles * 2 - 2);
+    return LIPASR_EUNSUPPORTED;
+  }
   LP_CHECK_ARG(sr_in >= 1000 && sr_in <= 384000, "lipasr_mfcc_plan: sr_in=%d outside [1000, 384000]", sr_in);
   LP_CHECK_ARG(n_samp >= 2 && batch_max >= 1, "lipasr_mfcc_plan: n_samp=%d batch_max=%d", n_samp, batch_max);
   DeviceGuard g(h->device);
@@ -846,7 +994,9 @@ int lipasr_mfcc_plan(lipasr_handle_t h, int sr_in, int n_samp, int batch_max) {
   p->identity = (sr_in == kSr);
   resampled_lengths(n_samp, sr_in, kSr, &p->n_valid, &p->n_y);
   if (p->n_y < 2) { delete p; set_error("lipasr_mfcc_plan: clip too short after resampling"); return LIPASR_EINVAL; }
-  p->n_frames = 1 + p->n_y / kHop;
+  p->n_fft = n_fft; p->hop = hop; p->dft = dft;
+  p->n_frames = 1 + p->n_y / hop;
+  if (p->n_y <= n_fft / 2) { delete p; set_error("lipasr_mfcc_plan: clip shorter than the reflect padding"); return LIPASR_EINVAL; }
   int rc = LIPASR_OK;
   if (!p->identity) {
     Polyphase pp = build_polyphase(sr_in, kSr);
@@ -882,8 +1032,21 @@ int lipasr_mfcc_plan(lipasr_handle_t h, int sr_in, int n_samp, int batch_max) {
       }
     if ((rc = upload(&p->d_twB, tb)) != LIPASR_OK) { mfcc_plan_free(p); return rc; }
   }
-  MelSparse ms = mel_sparse();
-  MelPairs mp = mel_pairs();
+  MelSparse ms = mel_sparse(n_fft);
+  if (dft) {
+    p->dft_tiles = (1 + n_fft / 2 + 31) / 32;
+    p->dft_krows = ((n_fft + 2 * kDftGroup - 1) / (2 * kDftGroup)) * (2 * kDftGroup);
+    p->dft_rpc = (p->n_y + 2 * (n_fft / 2) + hop - 1) / hop;
+    const size_t npad = ((size_t)batch_max * p->dft_rpc + kDftRows + 1) * hop + p->dft_krows;
+    if ((rc = upload(&p->d_dft, dft_table(n_fft, p->dft_krows, p->dft_tiles))) != LIPASR_OK) { mfcc_plan_free(p); return rc; }
+    if (hipMalloc(&p->d_ypad, npad * sizeof(float)) != hipSuccess || hipMemset(p->d_ypad, 0, npad * sizeof(float)) != hipSuccess) {
+      mfcc_plan_free(p);
+      set_error("lipasr_mfcc_plan_ex: padded-clip allocation failed");
+      return LIPASR_ENOMEM;
+    }
+  }
+  MelPairs mp = dft ? MelPairs() : mel_pairs();
+  if (dft) { mp.wlo.assign(1, 0.f); mp.whi.assign(1, 0.f); mp.start.assign(1, 0); mp.len.assign(1, 0); }
   if (!mp.ok) {
     mfcc_plan_free(p);
     set_error("lipasr_mfcc_plan: mel filter bank is not a two-filters-per-bin bank");

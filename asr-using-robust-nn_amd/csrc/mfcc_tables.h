@@ -113,10 +113,14 @@ inline Polyphase build_polyphase(int sr_orig, int sr_new) {
   return pp;
 }
 
-inline std::vector<float> hann_periodic() {
-  std::vector<float> w(kNFft);
-  for (int n = 0; n < kNFft; ++n) w[n] = (float)(0.5 - 0.5 * std::cos(2.0 * kPi * (double)n / (double)kNFft));
+inline std::vector<double> hann_periodic_f64(int n_fft) {
+  std::vector<double> w(n_fft);
+  for (int n = 0; n < n_fft; ++n) w[n] = 0.5 - 0.5 * std::cos(2.0 * kPi * (double)n / (double)n_fft);
   return w;
+}
+inline std::vector<float> hann_periodic(int n_fft = kNFft) {
+  std::vector<double> d = hann_periodic_f64(n_fft);
+  return std::vector<float>(d.begin(), d.end());
 }
 
 // exp(-2 pi i k / 2048), interleaved (cos, sin)
@@ -140,23 +144,26 @@ inline double mel_to_hz(double m) {
 }
 
 // librosa.filters.mel(sr=22050, n_fft=2048, n_mels=128, fmin=0, fmax=sr/2, htk=False, norm='slaney'),
-// dense float32 [128][1025]
-inline std::vector<float> mel_dense() {
-  std::vector<float> W((size_t)kNMels * kNBins, 0.0f);
-  std::vector<double> fftfreqs(kNBins), mel_f(kNMels + 2);
+// dense float32 [128][1 + n_fft/2].  The bin frequencies are librosa <= 0.9's fft_frequencies,
+// np.linspace(0, sr/2, 1 + n_fft//2) -- also for an odd n_fft (Speaker recognition, n_fft = 441), where it
+// differs from the true k*sr/n_fft grid; the reference's era of librosa is what is restated.
+inline std::vector<float> mel_dense(int n_fft = kNFft) {
+  const int n_bins = 1 + n_fft / 2;
+  std::vector<float> W((size_t)kNMels * n_bins, 0.0f);
+  std::vector<double> fftfreqs(n_bins), mel_f(kNMels + 2);
   const double fmax = (double)kSr / 2.0;
-  for (int i = 0; i < kNBins; ++i) fftfreqs[i] = fmax * (double)i / (double)(kNBins - 1);
+  for (int i = 0; i < n_bins; ++i) fftfreqs[i] = fmax * (double)i / (double)(n_bins - 1);
   const double m_lo = hz_to_mel(0.0), m_hi = hz_to_mel(fmax);
   for (int i = 0; i < kNMels + 2; ++i) mel_f[i] = mel_to_hz(m_lo + (m_hi - m_lo) * (double)i / (double)(kNMels + 1));
   for (int i = 0; i < kNMels; ++i) {
     const double fd0 = mel_f[i + 1] - mel_f[i], fd1 = mel_f[i + 2] - mel_f[i + 1];
     const float enorm = (float)(2.0 / (mel_f[i + 2] - mel_f[i]));
-    for (int b = 0; b < kNBins; ++b) {
+    for (int b = 0; b < n_bins; ++b) {
       const double lower = -(mel_f[i] - fftfreqs[b]) / fd0;
       const double upper = (mel_f[i + 2] - fftfreqs[b]) / fd1;
       double v = lower < upper ? lower : upper;
       if (v < 0.0) v = 0.0;
-      W[(size_t)i * kNBins + b] = (float)v * enorm;
+      W[(size_t)i * n_bins + b] = (float)v * enorm;
     }
   }
   return W;
@@ -166,19 +173,20 @@ struct MelSparse {
   std::vector<int> start, len, off;  // [128]
   std::vector<float> w;              // concatenated non-zero runs
 };
-inline MelSparse mel_sparse() {
+inline MelSparse mel_sparse(int n_fft = kNFft) {
+  const int n_bins = 1 + n_fft / 2;
   MelSparse s;
-  std::vector<float> W = mel_dense();
+  std::vector<float> W = mel_dense(n_fft);
   s.start.assign(kNMels, 0); s.len.assign(kNMels, 0); s.off.assign(kNMels, 0);
   for (int i = 0; i < kNMels; ++i) {
-    int lo = kNBins, hi = -1;
-    for (int b = 0; b < kNBins; ++b)
-      if (W[(size_t)i * kNBins + b] != 0.0f) { if (b < lo) lo = b; hi = b; }
+    int lo = n_bins, hi = -1;
+    for (int b = 0; b < n_bins; ++b)
+      if (W[(size_t)i * n_bins + b] != 0.0f) { if (b < lo) lo = b; hi = b; }
     s.off[i] = (int)s.w.size();
     if (hi >= lo) {
       s.start[i] = lo;
       s.len[i] = hi - lo + 1;
-      for (int b = lo; b <= hi; ++b) s.w.push_back(W[(size_t)i * kNBins + b]);
+      for (int b = lo; b <= hi; ++b) s.w.push_back(W[(size_t)i * n_bins + b]);
     }
   }
   return s;
@@ -221,6 +229,26 @@ inline MelPairs mel_pairs() {
   for (int m = 0; m < kNMels; ++m)
     if (mp.len[m] == 0) mp.start[m] = 0;
   return mp;
+}
+
+// Windowed real-DFT matrix for an STFT evaluated as a contraction (n_fft <= 512, any parity):
+//   T[k][t*64 + j]      =  hann[k] cos(2 pi k b / n_fft)     b = 32 t + j,  j < 32
+//   T[k][t*64 + 32 + j] = -hann[k] sin(2 pi k b / n_fft)
+// rows k >= n_fft and bins b > n_fft/2 are zero; k_rows rows of n_tiles*64 floats.  Angles are reduced
+// exactly (k*b mod n_fft) before the fp64 evaluation.
+inline std::vector<float> dft_table(int n_fft, int k_rows, int n_tiles) {
+  const int ld = n_tiles * 64, n_bins = 1 + n_fft / 2;
+  std::vector<float> T((size_t)k_rows * ld, 0.0f);
+  std::vector<double> w = hann_periodic_f64(n_fft);
+  for (int k = 0; k < n_fft; ++k)
+    for (int b = 0; b < n_bins; ++b) {
+      const long long r = ((long long)k * b) % n_fft;
+      const double ang = 2.0 * kPi * (double)r / (double)n_fft;
+      const int t = b >> 5, j = b & 31;
+      T[(size_t)k * ld + t * 64 + j] = (float)(w[k] * std::cos(ang));
+      T[(size_t)k * ld + t * 64 + 32 + j] = (float)(-w[k] * std::sin(ang));
+    }
+  return T;
 }
 
 // rows 0..19 of scipy.fftpack.dct(type=2, norm='ortho') over 128 points, float32 [20][128]

@@ -84,6 +84,7 @@ PROTOTYPES = {
     "lipasr_mlp_attack_step": (i32, [c_h, c_f, c_f, c_f, c_f, c_f, i32, f32, f32, c_s]),
     "lipasr_mlp_own_labels": (i32, [c_h, c_f, c_f, c_f, i32, c_f, c_s]),
     "lipasr_mfcc_plan": (i32, [c_h, i32, i32, i32]),
+    "lipasr_mfcc_plan_ex": (i32, [c_h, i32, i32, i32, i32, i32]),
     "lipasr_mfcc_dims": (i32, [c_h, PI, PI]),
     "lipasr_mfcc_f32": (i32, [c_h, c_f, i32, i32, c_f, c_f, c_f, c_s]),
     "lipasr_resample_f32": (i32, [c_h, c_f, i32, c_f, c_s]),

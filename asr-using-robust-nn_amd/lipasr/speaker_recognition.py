@@ -1,0 +1,141 @@
+"""Speaker-recognition variant of the path: the reference's second copy of the pipeline,
+``Speaker recognition/``, differs from the voice-digit one in three places and only those live here --
+
+* features: recordings already at 22 050 Hz are cut into 1-s windows (first and last second dropped) and each
+  window goes through ``librosa.feature.mfcc(win_length=441, n_fft=441, hop_length=220)`` -> 20 x 101 = 2020
+  (Speaker recognition/extract_features_construct_dataset.py:203-233);
+* classifier: 2020 inputs, 20 speakers, batch 64 (Speaker recognition/train_constraints.py:41,63-88;
+  train_no_constraints.py:52-74 for the baseline without BatchNorm / NonNeg);
+* the constraint in use is ``simple_norm_constraint(rho=1)`` (train_constraints.py:103).
+
+Constraints.py, the Lipschitz read-outs and the attacks are the same files as the voice-digit ones and are
+re-exported.  The window length is not a power of two (441 = 3^2 7^2), so the STFT runs on the short-window
+path of the MFCC plan (lipasr_mfcc_plan_ex: windowed real DFT as an fp32 MFMA contraction).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _native as N
+from .Constraints import customConstraint, norm_constraint, norm_constraint_FISTA, simple_norm_constraint  # noqa: F401
+from .extract_features_construct_dataset import (  # noqa: F401
+    N_MFCC,
+    MfccExtractor,
+    extract_features,
+    get_lipschitz_constrained,
+    get_norms,
+    get_upper_lipschitz,
+    read_wav,
+)
+from .keras import BatchNormalization, Dense, Dropout, Input, Model, NonNeg
+
+# the 20 speaker ids of the RoDigits split (extract_features_construct_dataset.py:11-12)
+digit = ['006', '041', '043', '044', '045', '046', '047', '048', '049', '105', '117', '118', '211', '212',
+         '213', '214', '215', '260', '261', '420']
+
+SR = 22050
+WIN_LENGTH = N_FFT = 441  # 20 ms at 22 050 Hz
+HOP_LENGTH = 220
+N_FRAMES = 1 + SR // HOP_LENGTH  # 101
+N_FEATURES = N_MFCC * N_FRAMES   # 2020
+N_SPEAKERS = 20
+
+
+class WindowMfcc:
+    """Plan + launch wrapper for [B, 22050] windows -> [B, 2020] on the short-window MFCC path."""
+
+    def __init__(self, batch_max=512, n_samp=SR, n_fft=N_FFT, hop_length=HOP_LENGTH, device=None):
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.h = N.get_handle(self.device.index)
+        self.batch_max, self.n_samp, self.n_fft, self.hop = int(batch_max), int(n_samp), int(n_fft), int(hop_length)
+        self._plan()
+
+    def _plan(self):
+        N.check(N.lib.lipasr_mfcc_plan_ex(self.h.h, SR, self.n_samp, self.batch_max, self.n_fft, self.hop))
+        self.h.mfcc_owner = self
+        ny, nf = C.c_int(), C.c_int()
+        N.check(N.lib.lipasr_mfcc_dims(self.h.h, C.byref(ny), C.byref(nf)))
+        self.n_y, self.n_frames = ny.value, nf.value
+
+    def __call__(self, windows, mean=None, scale=None, out=None):
+        if getattr(self.h, "mfcc_owner", None) is not self:
+            self._plan()
+        b = windows.shape[0]
+        if out is None:
+            out = torch.empty(b, N_MFCC * self.n_frames, device=self.device)
+        N.check(N.lib.lipasr_mfcc_from_22k(self.h.h, N.ptr(windows), b, self.n_y, self.n_frames, N.ptr(mean), N.ptr(scale),
+                                           N.ptr(out), N.stream_ptr()))
+        return out
+
+
+_window_mfcc = {}
+
+
+def mfcc_windows(windows, chunk=512):
+    """Batched tensor entry: float32 [N, 22050] windows (tensor or array) -> device tensor [N, 2020]."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    w = torch.as_tensor(np.asarray(windows, dtype=np.float32) if not torch.is_tensor(windows) else windows)
+    w = w.to(device=dev, dtype=torch.float32).contiguous()
+    key = (w.shape[1], dev.index)
+    ex = _window_mfcc.get(key)
+    if ex is None:
+        ex = _window_mfcc[key] = WindowMfcc(batch_max=chunk, n_samp=w.shape[1])
+    out = torch.empty(w.shape[0], N_MFCC * ex.n_frames, device=dev)
+    for s in range(0, w.shape[0], ex.batch_max):
+        ex(w[s:s + ex.batch_max], out=out[s:s + ex.batch_max])
+    return out
+
+
+def split_windows(raw_w, sampling_rate=SR):
+    """extract_features_construct_dataset.py:207-221: 1-s windows, first second and the tail dropped."""
+    window_length = 1 * sampling_rate
+    audio_length = int(len(raw_w) / window_length)
+    raw_w = raw_w[window_length:(audio_length - 1) * window_length]
+    audio_length = int(len(raw_w) / window_length)
+    return np.asarray(raw_w[:audio_length * window_length], dtype=np.float32).reshape(audio_length, window_length)
+
+
+def _load_22k(file_path):
+    """librosa.load(file_path, mono=True): decode, mono mix, resample to 22 050 Hz on the device if needed."""
+    x, sr = read_wav(file_path)
+    if sr == SR:
+        return x
+    ex = MfccExtractor(sr, len(x), 1)
+    return ex.resample(torch.as_tensor(x).cuda()[None])[0].cpu().numpy()
+
+
+def load_audio_dataset_and_labels(filenames, labels):
+    """extract_features_construct_dataset.py:203-233 -> (mfcc [num_seconds, 2020] float64, labels [num_seconds])."""
+    windows, local_labels = [], []
+    for i, file_path in enumerate(filenames):
+        w = split_windows(_load_22k(file_path))
+        windows.append(w)
+        local_labels.extend([labels[i]] * len(w))
+    if not windows or sum(len(w) for w in windows) == 0:
+        return np.zeros((0, N_FEATURES)), np.array(local_labels)
+    feats = mfcc_windows(np.concatenate(windows, axis=0))
+    return feats.cpu().numpy().astype(np.float64), np.array(local_labels)
+
+
+def get_model(**kw):
+    """Speaker recognition/train_constraints.py:63-88 (the voice-digit network with 2020 inputs, 20 outputs)."""
+    inp = Input((N_FEATURES,))
+    hdn = inp
+    for units, drop in ((1024, 0.1), (512, 0.1), (256, 0.1), (128, 0.0), (64, 0.0)):
+        hdn = Dense(units, activation="relu", kernel_constraint=NonNeg())(hdn)
+        hdn = BatchNormalization()(hdn)
+        if drop:
+            hdn = Dropout(drop)(hdn)
+    out = Dense(N_SPEAKERS, activation="softmax", kernel_constraint=NonNeg())(hdn)
+    return Model(inputs=inp, outputs=out, **kw)
+
+
+def get_model_unconstrained(**kw):
+    """Speaker recognition/train_no_constraints.py:52-74: plain Dense/ReLU stack, no BatchNorm, no Dropout."""
+    inp = Input((N_FEATURES,))
+    hdn = inp
+    for units in (1024, 512, 256, 128, 64):
+        hdn = Dense(units, activation="relu")(hdn)
+    out = Dense(N_SPEAKERS, activation="softmax")(hdn)
+    return Model(inputs=inp, outputs=out, **kw)

@@ -240,7 +240,14 @@ int lipasr_mlp_own_labels(lipasr_mlp_t m, const float* params, const float* bnst
  * lipasr_mfcc_plan builds the tables for (sr_in, n_samp) and allocates intermediates for
  * batch_max clips; it must precede the launch functions (not capturable itself). */
 int lipasr_mfcc_plan(lipasr_handle_t h, int sr_in, int n_samp, int batch_max);
-/* resampled length int(ceil(n_samp*22050/sr_in)) and frame count 1 + n_y/512 for a plan */
+/* Same with an explicit window: librosa.feature.mfcc(y, sr, n_fft=n_fft, win_length=n_fft,
+ * hop_length=hop).  (2048, 512) is the plan above (LDS Stockham FFT).  Any 32 <= n_fft <= 510 with
+ * 1 <= hop <= n_fft selects the short-window path, where the windowed real DFT is an fp32 MFMA
+ * contraction -- the Speaker-recognition features (Speaker recognition/
+ * extract_features_construct_dataset.py:224-226: win_length=441, n_fft=441, hop_length=220 on
+ * 1-s windows at 22 050 Hz -> 20 x 101 = 2020).  Other values: LIPASR_EUNSUPPORTED. */
+int lipasr_mfcc_plan_ex(lipasr_handle_t h, int sr_in, int n_samp, int batch_max, int n_fft, int hop);
+/* resampled length int(ceil(n_samp*22050/sr_in)) and frame count 1 + n_y/hop for a plan */
 int lipasr_mfcc_dims(lipasr_handle_t h, int* n_y, int* n_frames);
 
 /* wav: [batch][n_samp] float32 mono in [-1,1).  out: [batch][20*utterance_length].

@@ -270,19 +270,19 @@ def reflect_pad(y: np.ndarray, pad: int) -> np.ndarray:
     return np.pad(y, pad, mode="reflect")
 
 
-def power_spectrogram(y: np.ndarray, dtype=np.float32) -> np.ndarray:
-    """|STFT|^2 with librosa defaults (center=True, reflect, periodic Hann).  [1025, T].
+def power_spectrogram(y: np.ndarray, dtype=np.float32, n_fft: int = N_FFT, hop: int = HOP) -> np.ndarray:
+    """|STFT|^2 with librosa defaults (center=True, reflect, periodic Hann, win_length = n_fft).  [1 + n_fft//2, T].
 
     ``dtype=np.float32`` is the clean path (librosa.load returns float32, the STFT is stored complex64).
     ``dtype=np.float64`` is what librosa <= 0.9 does for the noisy-audio paths of VD/attacks.py, where
     ``raw_w + np.random.normal(...)`` is float64 and the STFT is inferred complex128."""
     y = np.asarray(y, dtype=dtype)
     ctype = np.complex64 if dtype == np.float32 else np.complex128
-    yp = reflect_pad(y, N_FFT // 2)
-    n_frames = 1 + (len(yp) - N_FFT) // HOP
-    idx = np.arange(N_FFT)[:, None] + HOP * np.arange(n_frames)[None, :]
-    frames = yp[idx]  # [2048, T]
-    win = hann_periodic(N_FFT)[:, None]  # float64
+    yp = reflect_pad(y, n_fft // 2)
+    n_frames = 1 + (len(yp) - n_fft) // hop
+    idx = np.arange(n_fft)[:, None] + hop * np.arange(n_frames)[None, :]
+    frames = yp[idx]  # [n_fft, T]
+    win = hann_periodic(n_fft)[:, None]  # float64
     spec = np.fft.rfft(win * frames, axis=0).astype(ctype)
     return (np.abs(spec) ** 2.0).astype(dtype)
 
@@ -297,13 +297,14 @@ def power_to_db(S: np.ndarray, amin: float = 1e-10, top_db: float = 80.0) -> np.
     return log_spec
 
 
-def mfcc_22k(y: np.ndarray, dtype=np.float32) -> np.ndarray:
-    """librosa.feature.mfcc(y=y, sr=22050) -> [20, T] in ``dtype`` (float32 clean path, float64 noisy path).
+def mfcc_22k(y: np.ndarray, dtype=np.float32, n_fft: int = N_FFT, hop: int = HOP) -> np.ndarray:
+    """librosa.feature.mfcc(y=y, sr=22050[, n_fft=, win_length=n_fft, hop_length=]) -> [20, T] in ``dtype``
+    (float32 clean path, float64 noisy path and the Speaker-recognition windows).
 
     The DCT is evaluated in float64 and rounded once; scipy.fftpack.dct ran in the input dtype, the
     difference is bounded in tests/test_oracle_cpu.py::test_oracle_rounding_budget."""
-    S = power_spectrogram(y, dtype)
-    mel = mel_filterbank().astype(dtype) @ S  # float32 sgemm in the reference's clean path
+    S = power_spectrogram(y, dtype, n_fft, hop)
+    mel = mel_filterbank(n_fft=n_fft).astype(dtype) @ S  # float32 sgemm in the reference's clean path
     db = power_to_db(mel)
     return (dct_matrix() @ db.astype(np.float64)).astype(dtype)
 
@@ -340,4 +341,27 @@ def compute_mfcc_batch(waves: np.ndarray, sr_in: int = 16000, utterance_length: 
     out = np.zeros((len(waves), N_MFCC * utterance_length))
     for i in range(len(waves)):
         out[i] = extract_features_wave(waves[i], sr_in, utterance_length, fast).flatten()
+    return out
+
+
+# --- Speaker recognition variant ------------------------------------------------------------------------------
+SR_N_FFT, SR_HOP = 441, 220  # SR/extract_features_construct_dataset.py:225-226 (20 ms window at 22 050 Hz)
+
+
+def sr_split_windows(raw_w: np.ndarray, sampling_rate: int = SR_TARGET) -> np.ndarray:
+    """SR/extract_features_construct_dataset.py:207-221: 1-s windows of a recording that is already at 22 050 Hz,
+    the first second and the last (more than one) second dropped.  -> [n_windows, sampling_rate]."""
+    window_length = 1 * sampling_rate
+    audio_length = int(len(raw_w) / window_length)
+    raw_w = raw_w[window_length:(audio_length - 1) * window_length]
+    audio_length = int(len(raw_w) / window_length)
+    return np.array([raw_w[i * window_length:(i + 1) * window_length] for i in range(audio_length)]).reshape(audio_length, window_length)
+
+
+def sr_mfcc_windows(windows: np.ndarray) -> np.ndarray:
+    """SR/extract_features_construct_dataset.py:223-232: librosa.feature.mfcc(y=float64 window, sr, win_length=441,
+    n_fft=441, hop_length=220) per window, [20, 101] flattened coefficient-major -> [N, 2020] float64."""
+    out = np.zeros((len(windows), N_MFCC * (1 + windows.shape[1] // SR_HOP)))
+    for j in range(len(windows)):
+        out[j] = mfcc_22k(np.asarray(windows[j], dtype=np.float64), np.float64, SR_N_FFT, SR_HOP).reshape(-1)
     return out

@@ -78,6 +78,19 @@ def vd_unconstrained_spec():
     return [LayerSpec(w[i], w[i + 1], i < 5, 0.4 if i < 5 else 0.0, False) for i in range(6)]
 
 
+def sr_constrained_spec():
+    """get_model() of SR/train_constraints.py:63-88: the same stack with 2020 inputs and 20 speakers."""
+    w = [2020, 1024, 512, 256, 128, 64, 20]
+    drop = [0.1, 0.1, 0.1, 0.0, 0.0, 0.0]
+    return [LayerSpec(w[i], w[i + 1], i < 5, drop[i], True) for i in range(6)]
+
+
+def sr_unconstrained_spec():
+    """get_model() of SR/train_no_constraints.py:52-74: Dense/ReLU only (BatchNorm and Dropout commented out)."""
+    w = [2020, 1024, 512, 256, 128, 64, 20]
+    return [LayerSpec(w[i], w[i + 1], False, 0.0, False) for i in range(6)]
+
+
 @dataclass
 class Params:
     W: list = field(default_factory=list)       # (in, out)
