@@ -53,8 +53,11 @@ struct MfccPlan {
   float* d_db = nullptr;   // [batch_max][n_frames][128]
   float* d_fmax = nullptr; // [batch_max][n_frames]
   // optional per-kernel HIP-event timing of lipasr_mfcc_f32 (bench.py's live roofline measurement)
-  std::vector<hipEvent_t> prof_events;  // 4 per call: start, after resample, after stft_mel, after dct
+  // 5 per extraction: resample start / end, stft_mel start / end, dct end.  The fused entry records all five; the split
+  // entries (lipasr_resample_f32 then lipasr_mfcc_from_22k, as the phase-locked pipeline issues them) fill the same slot.
+  std::vector<hipEvent_t> prof_events;
   int prof_cap = 0, prof_n = 0;
+  bool prof_half = false;  // slot prof_n already holds a resample timing
 };
 
 void mfcc_plan_free(MfccPlan* p) {
@@ -921,7 +924,7 @@ static int launch_resample(const MfccPlan* p, const float* wav, int batch, float
 }
 
 static int launch_from_22k(const MfccPlan* p, const float* y, int batch, int L, const double* am, const double* as,
-                           float* out, hipStream_t st, hipEvent_t mid = nullptr) {
+                           float* out, hipStream_t st, hipEvent_t mid = nullptr) {  // mid: recorded between stft_mel and dct
   StftArgs a;
   a.y = y; a.n_y = p->n_y; a.n_frames = p->n_frames; a.hann = p->d_hann;
   a.tw = reinterpret_cast<const float2*>(p->d_tw);
@@ -1096,7 +1099,16 @@ int lipasr_resample_f32(lipasr_handle_t h, const float* wav, int batch, float* y
   int rc = mfcc_check("lipasr_resample_f32", h, batch, 1);
   if (rc != LIPASR_OK) return rc;
   LP_CHECK_ARG(wav && y, "lipasr_resample_f32: null argument");
-  return launch_resample(h->mfcc, wav, batch, y, S(stream));
+  MfccPlan* p = h->mfcc;
+  hipEvent_t* ev = (p->prof_n < p->prof_cap) ? &p->prof_events[5 * (size_t)p->prof_n] : nullptr;
+  if (ev) LP_HIP(hipEventRecord(ev[0], S(stream)));
+  rc = launch_resample(p, wav, batch, y, S(stream));
+  if (rc != LIPASR_OK) return rc;
+  if (ev) {
+    LP_HIP(hipEventRecord(ev[1], S(stream)));
+    p->prof_half = true;
+  }
+  return LIPASR_OK;
 }
 
 int lipasr_mfcc_from_22k(lipasr_handle_t h, const float* y, int batch, int n_y, int utterance_length,
@@ -1106,7 +1118,18 @@ int lipasr_mfcc_from_22k(lipasr_handle_t h, const float* y, int batch, int n_y, 
   LP_CHECK_ARG(y && out, "lipasr_mfcc_from_22k: null argument");
   LP_CHECK_ARG(n_y == h->mfcc->n_y, "lipasr_mfcc_from_22k: n_y=%d but the plan was made for %d", n_y, h->mfcc->n_y);
   LP_CHECK_ARG((affine_mean == nullptr) == (affine_scale == nullptr), "lipasr_mfcc_from_22k: give both affine arrays or neither");
-  return launch_from_22k(h->mfcc, y, batch, utterance_length, affine_mean, affine_scale, out, S(stream));
+  MfccPlan* p = h->mfcc;
+  // timed only as the second half of a split extraction (a resample timing is already in the slot)
+  hipEvent_t* ev = (p->prof_half && p->prof_n < p->prof_cap) ? &p->prof_events[5 * (size_t)p->prof_n] : nullptr;
+  if (ev) LP_HIP(hipEventRecord(ev[2], S(stream)));
+  rc = launch_from_22k(p, y, batch, utterance_length, affine_mean, affine_scale, out, S(stream), ev ? ev[3] : nullptr);
+  if (rc != LIPASR_OK) return rc;
+  if (ev) {
+    LP_HIP(hipEventRecord(ev[4], S(stream)));
+    p->prof_half = false;
+    p->prof_n++;
+  }
+  return LIPASR_OK;
 }
 
 int lipasr_mfcc_f32(lipasr_handle_t h, const float* wav, int batch, int utterance_length, const double* affine_mean,
@@ -1116,15 +1139,18 @@ int lipasr_mfcc_f32(lipasr_handle_t h, const float* wav, int batch, int utteranc
   LP_CHECK_ARG(wav && out, "lipasr_mfcc_f32: null argument");
   LP_CHECK_ARG((affine_mean == nullptr) == (affine_scale == nullptr), "lipasr_mfcc_f32: give both affine arrays or neither");
   MfccPlan* p = h->mfcc;
-  hipEvent_t* ev = (p->prof_n < p->prof_cap) ? &p->prof_events[4 * (size_t)p->prof_n] : nullptr;
+  hipEvent_t* ev = (!p->prof_half && p->prof_n < p->prof_cap) ? &p->prof_events[5 * (size_t)p->prof_n] : nullptr;
   if (ev) LP_HIP(hipEventRecord(ev[0], S(stream)));
   rc = launch_resample(p, wav, batch, p->d_y, S(stream));
   if (rc != LIPASR_OK) return rc;
-  if (ev) LP_HIP(hipEventRecord(ev[1], S(stream)));
-  rc = launch_from_22k(p, p->d_y, batch, utterance_length, affine_mean, affine_scale, out, S(stream), ev ? ev[2] : nullptr);
+  if (ev) {
+    LP_HIP(hipEventRecord(ev[1], S(stream)));
+    LP_HIP(hipEventRecord(ev[2], S(stream)));
+  }
+  rc = launch_from_22k(p, p->d_y, batch, utterance_length, affine_mean, affine_scale, out, S(stream), ev ? ev[3] : nullptr);
   if (rc != LIPASR_OK) return rc;
   if (ev) {
-    LP_HIP(hipEventRecord(ev[3], S(stream)));
+    LP_HIP(hipEventRecord(ev[4], S(stream)));
     p->prof_n++;
   }
   return LIPASR_OK;
@@ -1135,13 +1161,14 @@ int lipasr_mfcc_profile_begin(lipasr_handle_t h, int max_calls) {
   if (!h->mfcc) { set_error("lipasr_mfcc_profile_begin: call lipasr_mfcc_plan first"); return LIPASR_ESTATE; }
   DeviceGuard g(h->device);
   MfccPlan* p = h->mfcc;
-  while ((int)p->prof_events.size() < 4 * max_calls) {
+  while ((int)p->prof_events.size() < 5 * max_calls) {
     hipEvent_t e;
     LP_HIP(hipEventCreate(&e));
     p->prof_events.push_back(e);
   }
   p->prof_cap = max_calls;
   p->prof_n = 0;
+  p->prof_half = false;
   return LIPASR_OK;
 }
 
@@ -1150,11 +1177,13 @@ int lipasr_mfcc_profile_end(lipasr_handle_t h, float* avg_ms3, int* n_calls) {
   if (!h->mfcc) { set_error("lipasr_mfcc_profile_end: call lipasr_mfcc_plan first"); return LIPASR_ESTATE; }
   MfccPlan* p = h->mfcc;
   double acc[3] = {0, 0, 0};
+  static const int kFrom[3] = {0, 2, 3}, kTo[3] = {1, 3, 4};
   for (int i = 0; i < p->prof_n; ++i) {
-    LP_HIP(hipEventSynchronize(p->prof_events[4 * (size_t)i + 3]));
+    hipEvent_t* ev = &p->prof_events[5 * (size_t)i];
+    LP_HIP(hipEventSynchronize(ev[4]));
     for (int k = 0; k < 3; ++k) {
       float ms = 0.0f;
-      LP_HIP(hipEventElapsedTime(&ms, p->prof_events[4 * (size_t)i + k], p->prof_events[4 * (size_t)i + k + 1]));
+      LP_HIP(hipEventElapsedTime(&ms, ev[kFrom[k]], ev[kTo[k]]));
       acc[k] += ms;
     }
   }
@@ -1162,6 +1191,7 @@ int lipasr_mfcc_profile_end(lipasr_handle_t h, float* avg_ms3, int* n_calls) {
   for (int k = 0; k < 3; ++k) avg_ms3[k] = p->prof_n ? (float)(acc[k] / p->prof_n) : 0.0f;
   p->prof_cap = 0;
   p->prof_n = 0;
+  p->prof_half = false;
   return LIPASR_OK;
 }
 

@@ -53,15 +53,16 @@ class MfccExtractor:
         N.check(N.lib.lipasr_mfcc_f32(self.h.h, N.ptr(waves), b, utterance_length, N.ptr(mean), N.ptr(scale), N.ptr(out), N.stream_ptr()))
         return out
 
-    def resample(self, waves):
+    def resample(self, waves, out=None):
         self._own()
-        y = torch.empty(waves.shape[0], self.n_y, device=self.device)
+        y = torch.empty(waves.shape[0], self.n_y, device=self.device) if out is None else out
         N.check(N.lib.lipasr_resample_f32(self.h.h, N.ptr(waves), waves.shape[0], N.ptr(y), N.stream_ptr()))
         return y
 
-    def from_22k(self, y, utterance_length=STANDARD_UTTERANCE_LENGTH, mean=None, scale=None):
+    def from_22k(self, y, utterance_length=STANDARD_UTTERANCE_LENGTH, mean=None, scale=None, out=None):
         self._own()
-        out = torch.empty(y.shape[0], N_MFCC * utterance_length, device=self.device)
+        if out is None:
+            out = torch.empty(y.shape[0], N_MFCC * utterance_length, device=self.device)
         N.check(N.lib.lipasr_mfcc_from_22k(self.h.h, N.ptr(y), y.shape[0], y.shape[1], utterance_length, N.ptr(mean), N.ptr(scale),
                                            N.ptr(out), N.stream_ptr()))
         return out
