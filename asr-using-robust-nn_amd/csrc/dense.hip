@@ -762,6 +762,29 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(BnBwdArgs p) {
   }
 }
 
+// upstream vector at the network output -> dz at the logits, one thread per row (class_gradient and the
+// optimisation-based attacks): on_logits: dz = v;  else out = softmax(z): dz = p * (v - sum_c p_c v_c)
+__global__ __launch_bounds__(256) void softmax_vjp_kernel(const float* __restrict__ z, const float* __restrict__ v, int B,
+                                                           int C, int on_logits, float* __restrict__ prob,
+                                                           float* __restrict__ dz) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  const float* zr = z + (size_t)b * C;
+  const float* vr = v + (size_t)b * C;
+  float mx = zr[0];
+  for (int c = 1; c < C; ++c) mx = fmaxf(mx, zr[c]);
+  float se = 0.0f;
+  for (int c = 0; c < C; ++c) se += expf(zr[c] - mx);
+  const float inv = 1.0f / se;
+  float dot = 0.0f;
+  for (int c = 0; c < C; ++c) dot = fmaf(expf(zr[c] - mx) * inv, vr[c], dot);
+  for (int c = 0; c < C; ++c) {
+    const float pc = expf(zr[c] - mx) * inv;
+    if (prob) prob[(size_t)b * C + c] = pc;
+    dz[(size_t)b * C + c] = on_logits ? vr[c] : pc * (vr[c] - dot);
+  }
+}
+
 // softmax + categorical cross-entropy from logits, one thread per row.
 //   prob (optional), dz = (p - y) * inv_batch (optional), loss_rows = -sum y log_softmax(z) (optional),
 //   correct_rows = [argmax p == argmax y] (optional), onehot_out = one-hot argmax z (optional)
@@ -1178,6 +1201,23 @@ int lipasr_mlp_attack_step(lipasr_mlp_t m, const float* params, const float* bns
   LP_CHECK_ARG(m->n_state == 0 || bnstate, "lipasr_mlp_attack_step: bnstate is null");
   LP_CHECK_ARG(eps >= 0.0f && !(alpha != alpha), "lipasr_mlp_attack_step: eps=%g alpha=%g", (double)eps, (double)alpha);
   return attack_common(m, params, bnstate, x_adv, y_onehot, batch, nullptr, x_adv, x0, alpha, eps, S(stream));
+}
+
+int lipasr_mlp_output_vjp(lipasr_mlp_t m, const float* params, const float* bnstate, const float* x, const float* v,
+                          int on_logits, int batch, float* probs_out, float* dx, lipasr_stream_t stream) {
+  int rc = check_batch("lipasr_mlp_output_vjp", m, batch);
+  if (rc != LIPASR_OK) return rc;
+  LP_CHECK_ARG(params && x && v && dx, "lipasr_mlp_output_vjp: null argument");
+  LP_CHECK_ARG(m->n_state == 0 || bnstate, "lipasr_mlp_output_vjp: bnstate is null");
+  hipStream_t st = S(stream);
+  float* lg = m->ws + m->offLogits;
+  rc = forward_infer(m, params, bnstate, x, batch, true, lg, st);
+  if (rc != LIPASR_OK) return rc;
+  const int C = m->L[m->n_layers - 1].n_out;
+  hipLaunchKernelGGL(softmax_vjp_kernel, dim3((batch + 255) / 256), dim3(256), 0, st, lg, v, batch, C, on_logits ? 1 : 0,
+                     probs_out, m->ws + m->offDzLast);
+  LP_LAUNCH_CHECK();
+  return backward_infer(m, params, bnstate, batch, dx, nullptr, nullptr, 0.0f, 0.0f, st);
 }
 
 }  // extern "C"

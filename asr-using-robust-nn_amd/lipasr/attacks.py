@@ -19,7 +19,7 @@ import torch
 
 from . import _native as N
 from .extract_features_construct_dataset import MfccExtractor, read_wav, _extractor
-from .keras import Model
+from .keras import Model, to_categorical
 
 
 def _dev():
@@ -96,6 +96,100 @@ class TensorFlowV2Classifier:
             xb, yb, ob = xt[s:s + bs], yt[s:s + bs], out[s:s + bs]
             N.check(N.lib.lipasr_mlp_input_grad(m._plan, N.ptr(m._params), N.ptr(m._bnstate), N.ptr(xb), N.ptr(yb), xb.shape[0], N.ptr(ob), N.stream_ptr()))
         return out.cpu().numpy()
+
+    def output_vjp_device(self, xt, vt, on_logits=False, probs_out=None):
+        """sum_c v[b, c] d out_c / dx on device tensors ([B, features], [B, classes]) -> [B, features]."""
+        m = self.model
+        out = torch.empty_like(xt)
+        bs = m._max_batch
+        for s in range(0, xt.shape[0], bs):
+            xb, vb, ob = xt[s:s + bs], vt[s:s + bs], out[s:s + bs]
+            pb = None if probs_out is None else probs_out[s:s + bs]
+            N.check(N.lib.lipasr_mlp_output_vjp(m._plan, N.ptr(m._params), N.ptr(m._bnstate), N.ptr(xb), N.ptr(vb), 1 if on_logits else 0,
+                                                xb.shape[0], N.ptr(pb), N.ptr(ob), N.stream_ptr()))
+        return out
+
+    def class_gradient(self, x, label=None):
+        """ART class_gradient: gradients of the model OUTPUT (softmax probabilities) w.r.t. x.
+        label None -> [B, nb_classes, features]; int or int array [B] -> [B, 1, features]."""
+        xt = _to_dev(x)
+        b = xt.shape[0]
+        if label is None:
+            cols = []
+            for c in range(self.nb_classes):
+                v = torch.zeros(b, self.nb_classes, device=xt.device)
+                v[:, c] = 1.0
+                cols.append(self.output_vjp_device(xt, v))
+            return torch.stack(cols, dim=1).cpu().numpy()
+        lab = torch.as_tensor(np.broadcast_to(np.asarray(label), (b,)).astype(np.int64), device=xt.device)
+        v = torch.zeros(b, self.nb_classes, device=xt.device)
+        v[torch.arange(b, device=xt.device), lab] = 1.0
+        return self.output_vjp_device(xt, v)[:, None, :].cpu().numpy()
+
+
+def random_targets(labels, nb_classes, rng=None):
+    """ART utils.random_targets: for every sample a uniformly drawn class different from ``labels`` -> one-hot."""
+    rng = np.random if rng is None else rng
+    labels = np.asarray(labels)
+    if labels.ndim > 1:
+        labels = labels.argmax(axis=1)
+    result = np.zeros(labels.shape, dtype=np.int64)
+    for c in range(nb_classes):
+        other = [k for k in range(nb_classes) if k != c]
+        sel = labels == c
+        result[sel] = rng.choice(other, size=int(sel.sum()))
+    return to_categorical(result, nb_classes)
+
+
+class SaliencyMapMethod:
+    """ART SaliencyMapMethod(classifier=, theta=, gamma=) (JSMA; attacks.py:546-550 uses theta=10, gamma=0.1) without
+    clip_values, as the reference runs it: while a sample's prediction differs from its target and at most ``gamma``
+    of its features were touched, add ``theta`` to the two features with the largest target-class gradient.
+    The class gradients and predictions run natively (lipasr_mlp_output_vjp / lipasr_mlp_predict).
+
+    ``max_iter`` bounds the loop: with no clip values ART's search space never shrinks, so a sample that never
+    reaches its target would loop forever there; None keeps ART's behaviour."""
+
+    def __init__(self, classifier, theta=0.1, gamma=1.0, batch_size=1, verbose=True, max_iter=None):
+        if not isinstance(classifier, TensorFlowV2Classifier):
+            raise TypeError("classifier must be a lipasr TensorFlowV2Classifier")
+        if not 0 < gamma <= 1:
+            raise ValueError("The total perturbation percentage `gamma` must be between 0 and 1.")
+        if batch_size <= 0:
+            raise ValueError("The batch size `batch_size` has to be positive.")
+        self.estimator, self.theta, self.gamma = classifier, float(theta), float(gamma)
+        self.batch_size, self.max_iter = int(batch_size), max_iter
+
+    def generate(self, x, y=None, rng=None):
+        est = self.estimator
+        m = est.model
+        xt = _to_dev(x)
+        adv = xt.clone()
+        nf = adv.shape[1]
+        preds = m.predict_device(xt).argmax(dim=1)
+        if y is None:
+            targets = torch.as_tensor(random_targets(preds.cpu().numpy(), est.nb_classes, rng).argmax(axis=1), device=xt.device)
+        else:
+            targets = torch.as_tensor(np.asarray(y.cpu() if torch.is_tensor(y) else y).argmax(axis=1), device=xt.device)
+        bs = min(self.batch_size, m._max_batch)
+        for s0 in range(0, adv.shape[0], bs):
+            batch = adv[s0:s0 + bs]
+            tgt = targets[s0:s0 + bs]
+            active = torch.nonzero(preds[s0:s0 + bs] != tgt)[:, 0]
+            all_feat = torch.zeros_like(batch)
+            it = 0
+            while active.numel() != 0 and (self.max_iter is None or it < self.max_iter):
+                v = torch.zeros(active.numel(), est.nb_classes, device=xt.device)
+                v[torch.arange(active.numel(), device=xt.device), tgt[active]] = 1.0
+                g = est.output_vjp_device(batch[active].contiguous(), v)
+                ind = torch.topk(g if self.theta > 0 else -g, 2, dim=1).indices
+                rows = active[:, None].expand(-1, 2)
+                all_feat[rows, ind] = 1.0
+                batch[rows, ind] += self.theta
+                cur = m.predict_device(batch.contiguous()).argmax(dim=1)
+                active = torch.nonzero((cur != tgt) & (all_feat.sum(dim=1) / nf <= self.gamma))[:, 0]
+                it += 1
+        return adv if torch.is_tensor(x) else adv.cpu().numpy().astype(np.asarray(x).dtype, copy=False)
 
 
 class _SignAttack:

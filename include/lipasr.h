@@ -218,6 +218,16 @@ int lipasr_mlp_predict(lipasr_mlp_t m, const float* params, const float* bnstate
 int lipasr_mlp_input_grad(lipasr_mlp_t m, const float* params, const float* bnstate, const float* x,
                           const float* y_onehot, int batch, float* dx, lipasr_stream_t stream);
 
+/* ART TensorFlowV2Classifier.class_gradient and the vector-Jacobian product the optimisation-based
+ * attacks are built on (SaliencyMapMethod, CarliniL2Method, CarliniLInfMethod call sites at
+ * attacks.py:538-645): dx[b] = sum_c v[b][c] * d out_c(x_b) / dx in inference mode, where out is the
+ * model output -- the softmax probabilities (on_logits = 0; what ART differentiates for a Keras model
+ * that ends in softmax) or the logits (on_logits = 1).  v: device [batch][classes] (a one-hot row gives
+ * one class gradient).  probs_out (device [batch][classes], may be NULL) receives softmax(f(x)). */
+int lipasr_mlp_output_vjp(lipasr_mlp_t m, const float* params, const float* bnstate, const float* x,
+                          const float* v, int on_logits, int batch, float* probs_out, float* dx,
+                          lipasr_stream_t stream);
+
 /* One fused FGSM/PGD iteration (attacks.py:506-510, 657-661): inference forward at x_adv, CE
  * gradient, backward to the input, and the K4 sign step applied in place on x_adv inside the last
  * backward GEMM's epilogue (dx never reaches memory). */

@@ -58,6 +58,54 @@ def sign_step(x_adv, x0, g, alpha, eps):
     return x0 + np.clip(xa - x0, -eps, eps)
 
 
+# ------------------------------------------------------------------ (f)-4: class gradients, JSMA
+def class_gradient(spec, p, x, labels):
+    """ART TensorFlowV2Classifier.class_gradient(x, label=labels)[:, 0, :]: gradient of the OUTPUT (softmax
+    probability) of class labels[b] w.r.t. x_b.  VD/attacks.py:538-645 are the call sites of the attacks using it."""
+    labels = np.broadcast_to(np.asarray(labels), (len(x),))
+    v = np.zeros((len(x), spec[-1].n_out))
+    v[np.arange(len(x)), labels] = 1.0
+    return mlp_ref.output_vjp_infer(spec, p, x, v, on_logits=False)[0]
+
+
+def jsma(spec, p, x, targets, theta=0.1, gamma=1.0, batch_size=1, max_iter=None):
+    """SaliencyMapMethod(classifier, theta, gamma).generate(x) (VD/attacks.py:546-550: theta=10, gamma=0.1), restated
+    from ART 1.9-1.10's published algorithm WITHOUT clip_values (the reference passes none): while the prediction
+    differs from the target and at most gamma of the features were touched, add theta to the two features with the
+    largest target-class gradient (smallest when theta < 0).  With no clip values the search space never shrinks,
+    so ART can loop forever on a sample that never reaches its target; ``max_iter`` (None = ART's behaviour) bounds
+    it.  ``targets`` (int array) replaces ART's unseeded random_targets draw."""
+    x = np.asarray(x)
+    adv = x.astype(np.float64 if x.dtype == np.float64 else np.float32).copy()
+    nf = adv.shape[1]
+    preds = np.concatenate([mlp_ref.forward_infer(spec, p, x[i:i + batch_size]) for i in range(0, len(x), batch_size)]).argmax(1)
+    targets = np.asarray(targets)
+    for s0 in range(0, len(adv), batch_size):
+        batch = adv[s0:s0 + batch_size]
+        tgt = targets[s0:s0 + batch_size]
+        cur = preds[s0:s0 + batch_size]
+        active = np.where(cur != tgt)[0]
+        all_feat = np.zeros_like(batch)
+        it = 0
+        while active.size != 0 and (max_iter is None or it < max_iter):
+            g = class_gradient(spec, p, batch[active], tgt[active])
+            if theta > 0:
+                ind = np.argpartition(g, -2, axis=1)[:, -2:]
+            else:
+                ind = np.argpartition(-g, -2, axis=1)[:, -2:]
+            all_feat[active, ind[:, 0]] = 1
+            all_feat[active, ind[:, 1]] = 1
+            tmp = batch[active]
+            tmp[np.arange(len(active)), ind[:, 0]] += theta
+            tmp[np.arange(len(active)), ind[:, 1]] += theta
+            batch[active] = tmp
+            cur = mlp_ref.forward_infer(spec, p, batch).argmax(1)
+            active = np.where((cur != tgt) & (all_feat.sum(axis=1) / nf <= gamma))[0]
+            it += 1
+        adv[s0:s0 + batch_size] = batch
+    return adv
+
+
 # ------------------------------------------------------------------ A12
 def add_white_noise(array, sigma, rng):
     """VD/attacks.py:73-86."""

@@ -221,6 +221,39 @@ def input_gradient_infer(spec, p: Params, x, y_onehot):
     return forward_backward(spec, p, x, y_onehot, masks=None, training=False, need_dx=True)["dx"]
 
 
+def output_vjp_infer(spec, p: Params, x, v, on_logits=False):
+    """sum_c v[b, c] * d out_c(x_b)/dx in inference mode; out = softmax probabilities (what ART's class_gradient
+    differentiates for a Keras model ending in softmax) or the logits.  Returns (dx, probs)."""
+    L = len(spec)
+    cache = []
+    h = x
+    for l, s in enumerate(spec):
+        z = h @ p.W[l] + p.b[l]
+        if l == L - 1:
+            logits = z
+            break
+        a = np.maximum(z, 0)
+        if s.bn:
+            rstd = 1.0 / np.sqrt(p.mov_var[l] + BN_EPS)
+            h = (a - p.mov_mean[l]) * rstd * p.gamma[l] + p.beta[l]
+            cache.append((a, p.gamma[l] * rstd))
+        else:
+            h = a
+            cache.append((a, None))
+    prob = softmax(logits)
+    g = np.asarray(v, dtype=prob.dtype)
+    if not on_logits:
+        g = prob * (g - (prob * g).sum(axis=1, keepdims=True))
+    for l in reversed(range(L)):
+        if l < L - 1:
+            a, scale = cache[l]
+            if scale is not None:
+                g = g * scale
+            g = g * (a > 0)
+        g = g @ p.W[l].T
+    return g, prob
+
+
 # ----------------------------------------------------------------------------- A4
 @dataclass
 class AdamState:

@@ -140,3 +140,67 @@ def test_device_noise_statistics(cuda):
     assert np.abs(clean - M.compute_mfcc_batch(waves)).max() < 2e-2
     loud = noisy_audio_to_mfcc(waves, 16000, sigma=0.05, seed=4).cpu().numpy()
     assert np.abs(loud - clean).max() > 1.0
+
+
+def test_class_gradient_and_output_vjp(cuda):
+    """ART class_gradient: gradients of the softmax outputs, and the logits variant of the same VJP."""
+    from lipasr.attacks import TensorFlowV2Classifier
+
+    spec, p, m = _setup(7)
+    clf = TensorFlowV2Classifier(model=m, nb_classes=10, input_shape=(880,))
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((37, 880)).astype(np.float32)
+    labels = rng.integers(0, 10, 37)
+    p64 = p.astype(np.float64)
+    want = A.class_gradient(spec, p64, x.astype(np.float64), labels)
+    got = clf.class_gradient(x, label=labels)
+    assert got.shape == (37, 1, 880)
+    scale = np.abs(want).max()
+    assert np.abs(got[:, 0] - want).max() <= 2e-5 * scale
+    # one class for every sample, and the full Jacobian
+    got3 = clf.class_gradient(x[:5], label=3)
+    assert np.abs(got3[:, 0] - A.class_gradient(spec, p64, x[:5].astype(np.float64), 3)).max() <= 2e-5 * scale
+    jac = clf.class_gradient(x[:5])
+    assert jac.shape == (5, 10, 880)
+    assert np.abs(jac[:, 3] - got3[:, 0]).max() == 0.0
+    assert np.abs(jac.sum(axis=1)).max() <= 1e-5 * scale  # probabilities sum to one: their gradients cancel
+    # arbitrary upstream vector at the logits
+    v = rng.standard_normal((37, 10)).astype(np.float32)
+    probs = torch.empty(37, 10, device="cuda")
+    gl = clf.output_vjp_device(dev(x), dev(v), on_logits=True, probs_out=probs).cpu().numpy()
+    want_l, want_p = P.output_vjp_infer(spec, p64, x.astype(np.float64), v.astype(np.float64), on_logits=True)
+    assert np.abs(gl - want_l).max() <= 2e-5 * np.abs(want_l).max()
+    np.testing.assert_allclose(probs.cpu().numpy(), want_p, atol=2e-6)
+
+
+@pytest.mark.parametrize("theta,gamma,bs", [(10.0, 0.1, 1), (2.0, 0.05, 8), (-3.0, 0.1, 4)])
+def test_jsma_matches_oracle(cuda, theta, gamma, bs):
+    """SaliencyMapMethod (attacks.py:546-550: theta=10, gamma=0.1) against the restated ART loop, targets injected.
+
+    The loop is discrete (pick two features, add theta, re-predict): it matches the oracle exactly unless two
+    class-gradient entries tie to within fp32 noise, so samples are compared on the set of perturbed features."""
+    from lipasr.attacks import SaliencyMapMethod, TensorFlowV2Classifier, random_targets
+
+    spec, p, m = _setup(9)
+    clf = TensorFlowV2Classifier(model=m, nb_classes=10, input_shape=(880,))
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((24, 880)).astype(np.float32)
+    p64 = p.astype(np.float64)
+    preds = P.forward_infer(spec, p64, x.astype(np.float64)).argmax(1)
+    y = random_targets(preds, 10, np.random.RandomState(1))
+    assert y.shape == (24, 10) and np.all(y.argmax(1) != preds)
+    atk = SaliencyMapMethod(classifier=clf, theta=theta, gamma=gamma, batch_size=bs, max_iter=200)
+    got = atk.generate(x=x, y=y)
+    want = A.jsma(spec, p64, x, y.argmax(1), theta=theta, gamma=gamma, batch_size=bs, max_iter=200)
+    assert got.shape == x.shape and got.dtype == x.dtype
+    same = [np.array_equal(np.nonzero(got[i] != x[i])[0], np.nonzero(want[i] != x[i])[0]) for i in range(24)]
+    assert np.mean(same) >= 0.9, np.mean(same)
+    for i in np.nonzero(same)[0]:
+        np.testing.assert_allclose(got[i], want[i], atol=1e-4)
+    d = got - x
+    assert np.all(np.abs(d / theta - np.round(d / theta)) < 1e-4)        # every change is a whole number of thetas
+    assert np.all((d != 0).sum(axis=1) / 880.0 <= gamma + 2.0 / 880.0)   # the gamma budget, up to the last pair
+    # y=None draws ART's random targets; the input array is left untouched
+    x_copy = x.copy()
+    adv = SaliencyMapMethod(classifier=clf, theta=theta, gamma=gamma, batch_size=8, max_iter=50).generate(x=x[:8], rng=np.random.RandomState(0))
+    assert np.array_equal(x, x_copy) and adv.shape == (8, 880)
