@@ -192,6 +192,223 @@ class SaliencyMapMethod:
         return adv if torch.is_tensor(x) else adv.cpu().numpy().astype(np.asarray(x).dtype, copy=False)
 
 
+_TANH_SMOOTHER = 0.999999
+_C_UPPER_BOUND = 10e10
+
+
+def _to_tanh(x, lo, hi):
+    return torch.atanh((torch.minimum(torch.maximum(x, lo), hi) - lo) / (hi - lo) * (2 * _TANH_SMOOTHER) - _TANH_SMOOTHER)
+
+
+def _from_tanh(xt, lo, hi):
+    return (torch.tanh(xt) / _TANH_SMOOTHER + 1.0) / 2.0 * (hi - lo) + lo
+
+
+class _Carlini:
+    """Shared pieces of ART's Carlini & Wagner attacks as the reference calls them (attacks.py:571-645): untargeted,
+    y=None (labels := the estimator's own predictions), no clip_values.  ART evaluates the margin on the model
+    OUTPUT -- softmax probabilities for this Keras model -- so with the reference's confidence >= 1 the success test
+    can never hold; that behaviour is kept.  Predictions and the class-gradient difference run natively
+    (lipasr_mlp_predict, lipasr_mlp_output_vjp); the line-search bookkeeping is a handful of elementwise tensor
+    ops per iteration.  Restated from ART 1.9-1.10's published implementation (ART is absent: parity unpinned)."""
+
+    def __init__(self, classifier, confidence, targeted, learning_rate, max_iter, max_halving, max_doubling, batch_size):
+        if not isinstance(classifier, TensorFlowV2Classifier):
+            raise TypeError("classifier must be a lipasr TensorFlowV2Classifier")
+        if targeted:
+            raise NotImplementedError("the reference runs the untargeted attack")
+        if max_iter < 0 or max_halving < 1 or max_doubling < 1 or batch_size < 1:
+            raise ValueError("max_iter >= 0, max_halving >= 1, max_doubling >= 1 and batch_size >= 1 are required")
+        self.estimator, self.confidence, self.learning_rate = classifier, float(confidence), float(learning_rate)
+        self.max_iter, self.max_halving, self.max_doubling, self.batch_size = int(max_iter), int(max_halving), int(max_doubling), int(batch_size)
+
+    def _predict(self, xa):
+        return self.estimator.model.predict_device(xa.contiguous())
+
+    def _margin(self, z, target):
+        z_target = (z * target).sum(dim=1)
+        z_other = (z * (1 - target) + (z.min(dim=1).values - 1)[:, None] * target).max(dim=1).values
+        return torch.clamp(z_target - z_other + self.confidence, min=0.0)
+
+    def _grad_diff(self, z, target, xa):
+        other = (z * (1 - target) + (z.min(dim=1).values - 1)[:, None] * target).argmax(dim=1)
+        v = target.clone()                                   # +1 at the label (i_add) ...
+        v[torch.arange(z.shape[0], device=z.device), other] -= 1.0   # ... -1 at the best other class (i_sub)
+        return self.estimator.output_vjp_device(xa.contiguous(), v)
+
+    def _labels(self, xt, y):
+        if y is not None:
+            return _to_dev(y)
+        m = self.estimator.model
+        yb = torch.empty(xt.shape[0], m._n_classes, device=xt.device)
+        bs = m._max_batch
+        for s in range(0, xt.shape[0], bs):
+            N.check(N.lib.lipasr_mlp_own_labels(m._plan, N.ptr(m._params), N.ptr(m._bnstate), N.ptr(xt[s:s + bs]), xt[s:s + bs].shape[0],
+                                                N.ptr(yb[s:s + bs]), N.stream_ptr()))
+        return yb
+
+    def _line_search(self, n, active, loss, pert, lr, evaluate):
+        """ART's halving / doubling search on the per-sample learning rate; evaluate(sel, step) -> loss of the trial
+        points x_tanh[sel] + step * pert_rows.  Returns best_lr (0 where no trial improved the loss)."""
+        prev_loss, best_loss = loss.clone(), loss.clone()
+        best_lr = torch.zeros(n, device=loss.device)
+        halving = torch.zeros(n, device=loss.device)
+        idx = torch.nonzero(active)[:, 0]
+        for _ in range(self.max_halving):
+            do = loss[idx] >= prev_loss[idx]
+            if not bool(do.any()):
+                break
+            sel = idx[do]
+            loss[sel] = evaluate(sel, lr[sel], pert[do])
+            better = loss < best_loss
+            best_lr[better] = lr[better]
+            best_loss[better] = loss[better]
+            lr[sel] /= 2
+            halving[sel] += 1
+        lr[idx] *= 2
+        for _ in range(self.max_doubling):
+            do = (halving[idx] == 1) & (loss[idx] <= best_loss[idx])
+            if not bool(do.any()):
+                break
+            sel = idx[do]
+            lr[sel] *= 2
+            loss[sel] = evaluate(sel, lr[sel], pert[do])
+            better = loss < best_loss
+            best_lr[better] = lr[better]
+            best_loss[better] = loss[better]
+        lr[halving == 1] /= 2
+        return best_lr
+
+
+class CarliniL2Method(_Carlini):
+    """ART CarliniL2Method(classifier=, confidence=) (attacks.py:606-616: confidence in linspace(1, 300, 3))."""
+
+    def __init__(self, classifier, confidence=0.0, targeted=False, learning_rate=0.01, binary_search_steps=10, max_iter=10,
+                 initial_const=0.01, max_halving=5, max_doubling=5, batch_size=1, verbose=True):
+        super().__init__(classifier, confidence, targeted, learning_rate, max_iter, max_halving, max_doubling, batch_size)
+        self.binary_search_steps, self.initial_const = int(binary_search_steps), float(initial_const)
+
+    def generate(self, x, y=None):
+        xt = _to_dev(x)
+        adv = xt.clone()
+        lo = torch.tensor(float(xt.min()), device=xt.device)
+        hi = torch.tensor(float(xt.max()), device=xt.device)
+        yt = self._labels(xt, y)
+        bs = min(self.batch_size, self.estimator.model._max_batch)
+        for s0 in range(0, xt.shape[0], bs):
+            xb, yb = xt[s0:s0 + bs], yt[s0:s0 + bs]
+            n = xb.shape[0]
+            xb_tanh = _to_tanh(xb, lo, hi)
+            c_cur = torch.full((n,), self.initial_const, device=xt.device)
+            c_lower = torch.zeros(n, device=xt.device)
+            c_double = torch.ones(n, dtype=torch.bool, device=xt.device)
+            best_l2 = torch.full((n,), float("inf"), device=xt.device)
+            best_adv = xb.clone()
+
+            def loss_fn(sel, xa_sel):
+                l2 = ((xb[sel] - xa_sel) ** 2).sum(dim=1)
+                z = self._predict(xa_sel)
+                return z, l2, c_cur[sel] * self._margin(z, yb[sel]) + l2
+
+            everyone = torch.arange(n, device=xt.device)
+            for _bss in range(self.binary_search_steps):
+                if not bool((c_cur < _C_UPPER_BOUND).any()):
+                    break
+                lr = torch.full((n,), self.learning_rate, device=xt.device)
+                xa, xa_tanh = xb.clone(), xb_tanh.clone()
+                z, l2, loss = loss_fn(everyone, xa)
+                success = loss - l2 <= 0
+                overall = success.clone()
+                for _it in range(self.max_iter):
+                    improved = success & (l2 < best_l2)
+                    best_l2[improved] = l2[improved]
+                    best_adv[improved] = xa[improved]
+                    active = (c_cur < _C_UPPER_BOUND) & (lr > 0)
+                    if not bool(active.any()):
+                        break
+                    g = self._grad_diff(z[active], yb[active], xa[active])
+                    g = g * c_cur[active][:, None] + 2 * (xa[active] - xb[active])
+                    g = g * (hi - lo) * (1 - torch.tanh(xa_tanh[active]) ** 2) / (2 * _TANH_SMOOTHER)
+                    pert = -g
+
+                    def evaluate(sel, step, rows):
+                        new_x = _from_tanh(xa_tanh[sel] + step[:, None] * rows, lo, hi)
+                        _, l2[sel], ls = loss_fn(sel, new_x)
+                        return ls
+
+                    best_lr = self._line_search(n, active, loss, pert, lr, evaluate)
+                    idx = torch.nonzero(active)[:, 0]
+                    upd = best_lr[idx] > 0
+                    if bool(upd.any()):
+                        sel = idx[upd]
+                        xa_tanh[sel] = xa_tanh[sel] + best_lr[sel][:, None] * pert[upd]
+                        xa[sel] = _from_tanh(xa_tanh[sel], lo, hi)
+                        z[sel], l2[sel], loss[sel] = loss_fn(sel, xa[sel])
+                        success = loss - l2 <= 0
+                        overall = overall | success
+                improved = success & (l2 < best_l2)
+                best_l2[improved] = l2[improved]
+                best_adv[improved] = xa[improved]
+                c_double[overall] = False
+                c_old = c_cur.clone()
+                c_cur[overall] = c_lower[overall] + (c_cur - c_lower)[overall] / 2
+                fail = ~overall
+                c_lower[fail] = c_old[fail]
+                fd = fail & c_double
+                c_cur[fd] = c_cur[fd] * 2
+                nd = fail & ~c_double
+                c_cur[nd] = c_cur[nd] + (c_cur - c_lower)[nd] / 2
+            adv[s0:s0 + bs] = best_adv
+        return adv if torch.is_tensor(x) else adv.cpu().numpy().astype(np.asarray(x).dtype, copy=False)
+
+
+class CarliniLInfMethod(_Carlini):
+    """ART CarliniLInfMethod(classifier=, confidence=) (attacks.py:578-582: confidence = 10), eps = 0.3."""
+
+    def __init__(self, classifier, confidence=0.0, targeted=False, learning_rate=0.01, max_iter=10, max_halving=5, max_doubling=5,
+                 eps=0.3, batch_size=128, verbose=True):
+        super().__init__(classifier, confidence, targeted, learning_rate, max_iter, max_halving, max_doubling, batch_size)
+        if eps <= 0:
+            raise ValueError("The eps parameter must be strictly positive.")
+        self.eps = float(eps)
+
+    def generate(self, x, y=None):
+        xt = _to_dev(x)
+        adv = xt.clone()
+        yt = self._labels(xt, y)
+        bs = min(self.batch_size, self.estimator.model._max_batch)
+        for s0 in range(0, xt.shape[0], bs):
+            xb, yb = xt[s0:s0 + bs], yt[s0:s0 + bs]
+            n = xb.shape[0]
+            lo, hi = xb - self.eps, xb + self.eps
+            xa, xa_tanh = xb.clone(), _to_tanh(xb, lo, hi)
+            z = self._predict(xa)
+            loss = self._margin(z, yb)
+            lr = torch.full((n,), self.learning_rate, device=xt.device)
+            for _it in range(self.max_iter):
+                active = (loss > 0) & (lr > 0)
+                if not bool(active.any()):
+                    break
+                g = self._grad_diff(z[active], yb[active], xa[active])
+                pert = -(g * (hi - lo)[active] * (1 - torch.tanh(xa_tanh[active]) ** 2) / (2 * _TANH_SMOOTHER))
+
+                def evaluate(sel, step, rows):
+                    new_x = _from_tanh(xa_tanh[sel] + step[:, None] * rows, lo[sel], hi[sel])
+                    return self._margin(self._predict(new_x), yb[sel])
+
+                best_lr = self._line_search(n, active, loss, pert, lr, evaluate)
+                idx = torch.nonzero(active)[:, 0]
+                upd = best_lr[idx] > 0
+                if bool(upd.any()):
+                    sel = idx[upd]
+                    xa_tanh[sel] = xa_tanh[sel] + best_lr[sel][:, None] * pert[upd]
+                    xa[sel] = _from_tanh(xa_tanh[sel], lo[sel], hi[sel])
+                z = self._predict(xa)
+                loss = self._margin(z, yb)
+            adv[s0:s0 + bs] = xa
+        return adv if torch.is_tensor(x) else adv.cpu().numpy().astype(np.asarray(x).dtype, copy=False)
+
+
 class _SignAttack:
     def __init__(self, estimator, eps, eps_step, max_iter, batch_size, norm, targeted, num_random_init):
         if not isinstance(estimator, TensorFlowV2Classifier):

@@ -106,6 +106,215 @@ def jsma(spec, p, x, targets, theta=0.1, gamma=1.0, batch_size=1, max_iter=None)
     return adv
 
 
+# ------------------------------------------------------------------ (f)-4: Carlini & Wagner, as ART runs them
+_TANH_SMOOTHER = 0.999999
+_C_UPPER_BOUND = 10e10
+
+
+def _to_tanh(x, lo, hi):
+    """art.utils.original_to_tanh: arctanh(((x - lo) / (hi - lo) * 2 - 1) * smoother)."""
+    return np.arctanh((np.clip(x, lo, hi) - lo) / (hi - lo) * 2 * _TANH_SMOOTHER - _TANH_SMOOTHER)
+
+
+def _from_tanh(xt, lo, hi):
+    """art.utils.tanh_to_original: (tanh(xt) / smoother + 1) / 2 * (hi - lo) + lo."""
+    return (np.tanh(xt) / _TANH_SMOOTHER + 1.0) / 2.0 * (hi - lo) + lo
+
+
+def _cw_margin(z, target, confidence, targeted=False):
+    """ART's rearranged C&W term on the model OUTPUT z (softmax probabilities for this Keras model):
+    max(z_target - z_other + confidence, 0) untargeted."""
+    z_target = np.sum(z * target, axis=1)
+    z_other = np.max(z * (1 - target) + (np.min(z, axis=1) - 1)[:, None] * target, axis=1)
+    if targeted:
+        return np.maximum(z_other - z_target + confidence, 0.0)
+    return np.maximum(z_target - z_other + confidence, 0.0)
+
+
+def _cw_class_grad_diff(spec, p, z, target, x_adv, targeted=False):
+    """class_gradient(x_adv, label=i_add) - class_gradient(x_adv, label=i_sub) (ART _loss_gradient)."""
+    other = np.argmax(z * (1 - target) + (np.min(z, axis=1) - 1)[:, None] * target, axis=1)
+    tgt = np.argmax(target, axis=1)
+    i_add, i_sub = (other, tgt) if targeted else (tgt, other)
+    v = np.zeros_like(z)
+    v[np.arange(len(z)), i_add] += 1.0
+    v[np.arange(len(z)), i_sub] -= 1.0
+    return mlp_ref.output_vjp_infer(spec, p, x_adv, v, on_logits=False)[0]
+
+
+def carlini_l2(spec, p, x, confidence=0.0, learning_rate=0.01, binary_search_steps=10, max_iter=10, initial_const=0.01,
+               max_halving=5, max_doubling=5, batch_size=1, y=None, dtype=np.float64):
+    """CarliniL2Method(classifier, confidence).generate(x) (VD/attacks.py:606-616), untargeted, no clip_values
+    (then ART takes clip_min, clip_max = min(x), max(x)), restated from ART 1.9-1.10's published implementation:
+    binary search over c, gradient steps in tanh space with a halving / doubling line search on the learning rate.
+    PARITY UNPINNED (ART absent): written from the algorithm as published; the bookkeeping may differ in detail."""
+    x = np.asarray(x, dtype=dtype)  # ART works in float32 (ART_NUMPY_DTYPE); float64 is the reference-grade evaluation
+    x_adv = x.copy()
+    lo, hi = dtype(np.amin(x)), dtype(np.amax(x))
+    y = _own_labels(spec, p, x, batch_size) if y is None else np.asarray(y, dtype=dtype)
+    predict = lambda a: mlp_ref.forward_infer(spec, p, a)
+
+    def loss_fn(xb, xa, yb, c):
+        l2 = np.sum(np.square(xb - xa), axis=1)
+        z = predict(xa)
+        return z, l2, c * _cw_margin(z, yb, confidence) + l2
+
+    for s0 in range(0, len(x), batch_size):
+        xb, yb = x[s0:s0 + batch_size], y[s0:s0 + batch_size]
+        n = len(xb)
+        xb_tanh = _to_tanh(xb, lo, hi)
+        c_cur = initial_const * np.ones(n, dtype=dtype)
+        c_lower = np.zeros(n, dtype=dtype)
+        c_double = np.ones(n) > 0
+        best_l2 = np.inf * np.ones(n, dtype=dtype)
+        best_adv = xb.copy()
+        for _bss in range(binary_search_steps):
+            if int(np.sum(c_cur < _C_UPPER_BOUND)) == 0:
+                break
+            lr = learning_rate * np.ones(n, dtype=dtype)
+            xa = xb.copy()
+            xa_tanh = xb_tanh.copy()
+            z, l2, loss = loss_fn(xb, xa, yb, c_cur)
+            success = loss - l2 <= 0
+            overall = success.copy()
+            for _it in range(max_iter):
+                improved = success & (l2 < best_l2)
+                best_l2[improved] = l2[improved]
+                best_adv[improved] = xa[improved]
+                active = (c_cur < _C_UPPER_BOUND) & (lr > 0)
+                if int(np.sum(active)) == 0:
+                    break
+                # gradient of the loss in tanh space, negated
+                g = _cw_class_grad_diff(spec, p, z[active], yb[active], xa[active])
+                g = g * c_cur[active][:, None] + 2 * (xa[active] - xb[active])
+                g = g * (hi - lo) * (1 - np.square(np.tanh(xa_tanh[active]))) / (2 * _TANH_SMOOTHER)
+                pert = -g
+                prev_loss, best_loss = loss.copy(), loss.copy()
+                best_lr = np.zeros(n, dtype=dtype)
+                halving = np.zeros(n)
+                for _h in range(max_halving):
+                    do = loss[active] >= prev_loss[active]
+                    if int(np.sum(do)) == 0:
+                        break
+                    sel = active.copy()
+                    sel[active] = do
+                    new_tanh = xa_tanh[sel] + lr[sel][:, None] * pert[do]
+                    new_x = _from_tanh(new_tanh, lo, hi)
+                    _, l2[sel], loss[sel] = loss_fn(xb[sel], new_x, yb[sel], c_cur[sel])
+                    better = loss < best_loss
+                    best_lr[better] = lr[better]
+                    best_loss[better] = loss[better]
+                    lr[sel] /= 2
+                    halving[sel] += 1
+                lr[active] *= 2
+                for _d in range(max_doubling):
+                    do = (halving[active] == 1) & (loss[active] <= best_loss[active])
+                    if int(np.sum(do)) == 0:
+                        break
+                    sel = active.copy()
+                    sel[active] = do
+                    lr[sel] *= 2
+                    new_tanh = xa_tanh[sel] + lr[sel][:, None] * pert[do]
+                    new_x = _from_tanh(new_tanh, lo, hi)
+                    _, l2[sel], loss[sel] = loss_fn(xb[sel], new_x, yb[sel], c_cur[sel])
+                    better = loss < best_loss
+                    best_lr[better] = lr[better]
+                    best_loss[better] = loss[better]
+                lr[halving == 1] /= 2
+                upd = best_lr[active] > 0
+                if int(np.sum(upd)) > 0:
+                    sel = active.copy()
+                    sel[active] = upd
+                    xa_tanh[sel] = xa_tanh[sel] + best_lr[sel][:, None] * pert[upd]
+                    xa[sel] = _from_tanh(xa_tanh[sel], lo, hi)
+                    z[sel], l2[sel], loss[sel] = loss_fn(xb[sel], xa[sel], yb[sel], c_cur[sel])
+                    success = loss - l2 <= 0
+                    overall = overall | success
+            improved = success & (l2 < best_l2)
+            best_l2[improved] = l2[improved]
+            best_adv[improved] = xa[improved]
+            # binary search on c: halve towards the lower bound after a success, else raise the lower bound and double
+            c_double[overall] = False
+            c_old = c_cur.copy()
+            c_cur[overall] = c_lower[overall] + (c_cur - c_lower)[overall] / 2
+            fail = ~overall
+            c_lower[fail] = c_old[fail]
+            c_cur[fail & c_double] = c_cur[fail & c_double] * 2
+            nd = fail & ~c_double
+            c_cur[nd] = c_cur[nd] + (c_cur - c_lower)[nd] / 2
+        x_adv[s0:s0 + batch_size] = best_adv
+    return x_adv
+
+
+def carlini_linf(spec, p, x, confidence=0.0, learning_rate=0.01, max_iter=10, max_halving=5, max_doubling=5, eps=0.3,
+                 batch_size=128, y=None, dtype=np.float64):
+    """CarliniLInfMethod(classifier, confidence).generate(x) (VD/attacks.py:578-582), untargeted, no clip_values:
+    minimise the C&W margin alone inside the box [x - eps, x + eps] (the tanh change of variables makes the box
+    the constraint), same line search as the L2 attack; samples stop moving once the margin reaches 0.
+    PARITY UNPINNED (ART absent), restated from the published implementation."""
+    x = np.asarray(x, dtype=dtype)
+    x_adv = x.copy()
+    y = _own_labels(spec, p, x, batch_size) if y is None else np.asarray(y, dtype=dtype)
+    eps = dtype(eps)
+    predict = lambda a: mlp_ref.forward_infer(spec, p, a)
+    for s0 in range(0, len(x), batch_size):
+        xb, yb = x[s0:s0 + batch_size], y[s0:s0 + batch_size]
+        n = len(xb)
+        lo, hi = xb - eps, xb + eps
+        xa = xb.copy()
+        xa_tanh = _to_tanh(xb, lo, hi)
+        z = predict(xa)
+        loss = _cw_margin(z, yb, confidence)
+        lr = learning_rate * np.ones(n, dtype=dtype)
+        for _it in range(max_iter):
+            active = (loss > 0) & (lr > 0)
+            if int(np.sum(active)) == 0:
+                break
+            g = _cw_class_grad_diff(spec, p, z[active], yb[active], xa[active])
+            g = g * (hi - lo)[active] * (1 - np.square(np.tanh(xa_tanh[active]))) / (2 * _TANH_SMOOTHER)
+            pert = -g
+            prev_loss, best_loss = loss.copy(), loss.copy()
+            best_lr = np.zeros(n, dtype=dtype)
+            halving = np.zeros(n)
+            for _h in range(max_halving):
+                do = loss[active] >= prev_loss[active]
+                if int(np.sum(do)) == 0:
+                    break
+                sel = active.copy()
+                sel[active] = do
+                new_x = _from_tanh(xa_tanh[sel] + lr[sel][:, None] * pert[do], lo[sel], hi[sel])
+                loss[sel] = _cw_margin(predict(new_x), yb[sel], confidence)
+                better = loss < best_loss
+                best_lr[better] = lr[better]
+                best_loss[better] = loss[better]
+                lr[sel] /= 2
+                halving[sel] += 1
+            lr[active] *= 2
+            for _d in range(max_doubling):
+                do = (halving[active] == 1) & (loss[active] <= best_loss[active])
+                if int(np.sum(do)) == 0:
+                    break
+                sel = active.copy()
+                sel[active] = do
+                lr[sel] *= 2
+                new_x = _from_tanh(xa_tanh[sel] + lr[sel][:, None] * pert[do], lo[sel], hi[sel])
+                loss[sel] = _cw_margin(predict(new_x), yb[sel], confidence)
+                better = loss < best_loss
+                best_lr[better] = lr[better]
+                best_loss[better] = loss[better]
+            lr[halving == 1] /= 2
+            upd = best_lr[active] > 0
+            if int(np.sum(upd)) > 0:
+                sel = active.copy()
+                sel[active] = upd
+                xa_tanh[sel] = xa_tanh[sel] + best_lr[sel][:, None] * pert[upd]
+                xa[sel] = _from_tanh(xa_tanh[sel], lo[sel], hi[sel])
+            z = predict(xa)
+            loss = _cw_margin(z, yb, confidence)
+        x_adv[s0:s0 + batch_size] = xa
+    return x_adv
+
+
 # ------------------------------------------------------------------ A12
 def add_white_noise(array, sigma, rng):
     """VD/attacks.py:73-86."""

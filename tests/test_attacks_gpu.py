@@ -204,3 +204,76 @@ def test_jsma_matches_oracle(cuda, theta, gamma, bs):
     x_copy = x.copy()
     adv = SaliencyMapMethod(classifier=clf, theta=theta, gamma=gamma, batch_size=8, max_iter=50).generate(x=x[:8], rng=np.random.RandomState(0))
     assert np.array_equal(x, x_copy) and adv.shape == (8, 880)
+
+
+def _small_net(seed=21):
+    """A small BN network whose decision margins are wide enough that the attacks have something to do."""
+    spec = [P.LayerSpec(40, 32, True, 0.0, True), P.LayerSpec(32, 16, True, 0.0, True), P.LayerSpec(16, 5, False, 0.0, True)]
+    p = P.init_params(spec, seed=seed, dtype=np.float32, nonneg_init=False)
+    rng = np.random.default_rng(seed)
+    for l, s in enumerate(spec):
+        p.W[l] = (p.W[l] * 3.0).astype(np.float32)
+        if s.bn:
+            p.mov_mean[l] = (0.2 * rng.standard_normal(s.n_out)).astype(np.float32)
+            p.mov_var[l] = rng.uniform(0.5, 1.5, s.n_out).astype(np.float32)
+    m = build_model(spec, max_batch=64)
+    load_params(m, p)
+    return spec, p, m
+
+
+def test_carlini_l2_matches_restated_art(cuda):
+    """CarliniL2Method (attacks.py:606-616).  The attack is a sequence of discrete decisions (line search, binary
+    search) on float comparisons: parity is stated on what it returns -- which samples are moved, how far, and that
+    moved samples change their label -- plus the reference's own regime (confidence >= 1 on softmax outputs), where
+    ART's success test cannot hold and generate() returns its input."""
+    from lipasr.attacks import CarliniL2Method, TensorFlowV2Classifier
+
+    spec, p, m = _small_net()
+    clf = TensorFlowV2Classifier(model=m, nb_classes=5, input_shape=(40,))
+    x = np.random.default_rng(2).standard_normal((12, 40)).astype(np.float32)
+    p64 = p.astype(np.float64)
+    want = A.carlini_l2(spec, p64, x, confidence=0.0, batch_size=4)
+    got = CarliniL2Method(classifier=clf, confidence=0.0, batch_size=4).generate(x=x)
+    assert got.shape == x.shape and got.dtype == x.dtype
+    d_got, d_want = np.linalg.norm(got - x, axis=1), np.linalg.norm(want - x, axis=1)
+    moved_got, moved_want = d_got > 0, d_want > 0
+    assert moved_want.sum() >= 4, "the fixture should contain samples the attack can move"
+    assert (moved_got == moved_want).mean() >= 0.9
+    both = moved_got & moved_want
+    np.testing.assert_allclose(d_got[both], d_want[both], rtol=0.15)
+    lab = np.eye(5)[P.forward_infer(spec, p64, x.astype(np.float64)).argmax(1)]
+    margin = A._cw_margin(P.forward_infer(spec, p64, got.astype(np.float64)), lab, 0.0)
+    # returned points satisfy ART's success test z_label - z_other <= 0 (minimal-distortion points sit ON the
+    # decision boundary, so the float64 re-evaluation is allowed fp32 noise) ...
+    assert np.all(margin[moved_got] <= 1e-5)
+    assert np.array_equal(got[~moved_got], x[~moved_got])    # ... or are the untouched input
+    # the reference's regime
+    same = CarliniL2Method(classifier=clf, confidence=150.5, batch_size=6, binary_search_steps=2, max_iter=3).generate(x=x)
+    assert np.array_equal(same, x)
+    assert np.array_equal(A.carlini_l2(spec, p64, x[:3], confidence=150.5, batch_size=3, binary_search_steps=2, max_iter=3), x[:3].astype(np.float64))
+
+
+def test_carlini_linf_matches_restated_art(cuda):
+    """CarliniLInfMethod (attacks.py:578-582): the iterate stays in the eps box; with confidence 0 samples stop once
+    misclassified; with the reference's confidence = 10 every sample keeps descending for max_iter steps."""
+    from lipasr.attacks import CarliniLInfMethod, TensorFlowV2Classifier
+
+    spec, p, m = _small_net()
+    clf = TensorFlowV2Classifier(model=m, nb_classes=5, input_shape=(40,))
+    x = np.random.default_rng(3).standard_normal((16, 40)).astype(np.float32)
+    p64 = p.astype(np.float64)
+    for conf in (0.0, 10.0):
+        # ART iterates in float32 (ART_NUMPY_DTYPE): saturated samples (p_label = 1 - 1e-7) stall there, and so do we
+        want = A.carlini_linf(spec, p, x, confidence=conf, eps=0.3, batch_size=8, dtype=np.float32)
+        got = CarliniLInfMethod(classifier=clf, confidence=conf, eps=0.3, batch_size=8).generate(x=x)
+        assert np.abs(got - x).max() <= 0.3 * (1 + 1e-5)
+        # same own-prediction margin after the attack, sample by sample (the path there may differ in float noise)
+        y = P.forward_infer(spec, p64, x.astype(np.float64))
+        lab = np.eye(5)[y.argmax(1)]
+        m_got = A._cw_margin(P.forward_infer(spec, p64, got.astype(np.float64)), lab, conf)
+        m_want = A._cw_margin(P.forward_infer(spec, p64, want.astype(np.float64)), lab, conf)
+        m_0 = A._cw_margin(y, lab, conf)
+        assert np.all(m_got <= m_0 + 1e-6)                       # never worse than the start
+        assert np.mean(np.abs(m_got - m_want) <= 0.05 * np.maximum(m_0, 1e-3)) >= 0.8
+        if conf == 0.0:
+            assert (m_got == 0).sum() >= 1
