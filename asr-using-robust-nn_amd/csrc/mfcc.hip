@@ -772,45 +772,72 @@ __global__ __launch_bounds__(64 * kDftMaxTiles) void dft_mel_kernel(DftArgs a) {
 // ---------------------------------------------------------------------------------------------
 // stage 3: top_db floor, DCT, layout
 // ---------------------------------------------------------------------------------------------
-constexpr int kDctFrames = 64;  // frames per workgroup (blockIdx.y = chunk): LDS stays 43 KB whatever the clip length
+constexpr int kDctFrames = 64;  // frames per workgroup (blockIdx.y = chunk): LDS stays 33 kB whatever the clip length
 
-__global__ __launch_bounds__(256) void dct_kernel(const float* __restrict__ db, const float* __restrict__ frame_max,
+// One workgroup = one clip x 64 output frames, two wavefronts (32 frames each):
+//   out[c][t] = sum_m D[c][m] * max(dB[t][m], clipmax - 80)      c < 20 (padded to 32), m < 128
+// as a 32 x 32 x 128 contraction per wavefront on v_mfma_f32_32x32x2_f32 (the same ascending-m fp32 fma chain a
+// scalar loop would run): the DCT rows are the A operand (64 registers per lane, loaded from the L2-resident table
+// while the dB tile is on its way), the clamped dB tile is staged transposed in LDS (row stride 65: unit-stride,
+// conflict-free B-operand reads).  28 -> 10 us per 1024 clips against the one-output-per-thread LDS loop.
+__global__ __launch_bounds__(128) void dct_kernel(const float* __restrict__ db, const float* __restrict__ frame_max,
                                                    int n_frames, int L, const float* __restrict__ dct,
                                                    const double* __restrict__ aff_mean,
                                                    const double* __restrict__ aff_scale, float* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  __shared__ float red[4];
-  const int tid = threadIdx.x, u = blockIdx.x;
+  __shared__ float dbs[128 * (kDctFrames + 1)];  // [m][t]
+  __shared__ float red[2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, u = blockIdx.x;
+  const int li = lane & 31, h = lane >> 5;
   const int t0 = blockIdx.y * kDctFrames;             // first output frame of this chunk
   const int tl = min(kDctFrames, L - t0);             // output frames of this chunk (incl. zero padding)
   const int tu = max(0, min(n_frames - t0, tl));      // of which computed from the spectrogram
-  const int tp = kDctFrames | 1;                      // odd row stride: conflict-free transposed store
-  float* dbs = sm;                                    // [128][tp]
-  float* ds = sm + 128 * tp;                          // [20][128]
+  constexpr int tp = kDctFrames + 1;
+  // dB tile: 64 frames x 128 mels = 64 floats per thread, ALL in flight at once (a plain loop keeps one load in
+  // flight per thread, and every load here is a cold-L2 round trip: that was 28 of the old kernel's 30 us)
+  const float* src = db + ((size_t)u * n_frames + t0) * 128;
+  const int n_valid = tu * 128;
+  float stage[64];
+#pragma unroll
+  for (int j = 0; j < 64; ++j) {
+    const int i = tid + 128 * j;
+    stage[j] = (i < n_valid) ? src[i] : 0.0f;
+  }
   float mx = -INFINITY;
-  for (int t = tid; t < n_frames; t += 256) mx = fmaxf(mx, frame_max[(size_t)u * n_frames + t]);  // whole clip
+  for (int t = tid; t < n_frames; t += 128) mx = fmaxf(mx, frame_max[(size_t)u * n_frames + t]);  // whole clip
   mx = wave_max(mx);
-  if ((tid & 63) == 0) red[tid >> 6] = mx;
-  for (int i = tid; i < kNMfcc * 128; i += 256) ds[i] = dct[i];
+  if (lane == 0) red[wave] = mx;
   __syncthreads();
-  const float thr = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) - 80.0f;  // top_db = 80
-  for (int i = tid; i < tu * 128; i += 256) {
-    const int t = i >> 7, m = i & 127;
-    dbs[m * tp + t] = fmaxf(db[((size_t)u * n_frames + t0 + t) * 128 + m], thr);
+  const float thr = fmaxf(red[0], red[1]) - 80.0f;  // top_db = 80
+#pragma unroll
+  for (int j = 0; j < 64; ++j) {
+    const int i = tid + 128 * j;  // frame j, mel tid: consecutive lanes, consecutive banks
+    dbs[tid * tp + j] = (i < n_valid) ? fmaxf(stage[j], thr) : 0.0f;
   }
   __syncthreads();
+  // A operand (L2-resident 10 kB table): lane (li, h) holds D[li][2 s + h], s < 64 (rows >= 20 are zero)
+  float av[64];
+#pragma unroll
+  for (int s2 = 0; s2 < 64; ++s2) av[s2] = (li < kNMfcc) ? dct[li * 128 + 2 * s2 + h] : 0.0f;
+  rs_f32x16 acc;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+  const float* bp = dbs + h * tp + wave * 32 + li;
+#pragma unroll
+  for (int s2 = 0; s2 < 64; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s2], bp[2 * s2 * tp], acc, 0, 0, 0);
+  // C layout: row (coefficient) = (q & 3) + 8 (q >> 2) + 4 h, column (frame) = li
+  const int t = wave * 32 + li;
   const int n_out = kNMfcc * L;
-  for (int o = tid; o < kNMfcc * tl; o += 256) {
-    const int c = o / tl, t = o - c * tl;
-    float v = 0.0f;
-    if (t < tu) {
-      const float* dr = ds + c * 128;
-#pragma unroll 8
-      for (int m = 0; m < 128; ++m) v = fmaf(dr[m], dbs[m * tp + t], v);
+  if (t < tl) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int c = (q & 3) + 8 * (q >> 2) + 4 * h;
+      if (c < kNMfcc) {
+        float v = (t < tu) ? acc[q] : 0.0f;
+        const int oo = c * L + t0 + t;
+        if (aff_mean) v = (float)(((double)v - aff_mean[oo]) / aff_scale[oo]);
+        out[(size_t)u * n_out + oo] = v;
+      }
     }
-    const int oo = c * L + t0 + t;
-    if (aff_mean) v = (float)(((double)v - aff_mean[oo]) / aff_scale[oo]);
-    out[(size_t)u * n_out + oo] = v;
   }
 }
 
@@ -963,8 +990,7 @@ static int launch_from_22k(const MfccPlan* p, const float* y, int batch, int L, 
   }
   LP_LAUNCH_CHECK();
   if (mid) LP_HIP(hipEventRecord(mid, st));
-  const size_t lds = ((size_t)128 * (kDctFrames | 1) + kNMfcc * 128) * sizeof(float);
-  hipLaunchKernelGGL(dct_kernel, dim3(batch, (L + kDctFrames - 1) / kDctFrames), dim3(256), lds, st, p->d_db, p->d_fmax,
+  hipLaunchKernelGGL(dct_kernel, dim3(batch, (L + kDctFrames - 1) / kDctFrames), dim3(128), 0, st, p->d_db, p->d_fmax,
                      p->n_frames, L, p->d_dct, am, as, out);
   LP_LAUNCH_CHECK();
   return LIPASR_OK;
