@@ -28,7 +28,8 @@ enum Epi {
   EPI_SIGNSTEP = 5,
   EPI_BIAS_RELU_STATS = 6,  // training forward: a = relu(acc + b) and per-tile column sums of a, a^2
   EPI_DH_STATS = 7,         // training backward: g = acc * dropout and per-tile column sums of g, g * xhat
-  EPI_DZ_NOBN = 8           // training backward through Dropout -> ReLU without BatchNorm
+  EPI_DZ_NOBN = 8,          // training backward through Dropout -> ReLU without BatchNorm
+  EPI_BIAS_SOFTMAX_CE = 9   // last layer (N <= 32, one column tile): logits, softmax, CE loss and (p - y) / B in one
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -73,6 +74,13 @@ struct GemmArgs {
   DropArgs drop;           // EPI_DH_STATS / EPI_DZ_NOBN
   int ones_row;            // AMODE 1 only: row M-1 of op(A) is all ones (bias gradient = column sums of B)
   float* extra_out;        // its output row goes here instead of C
+  // EPI_BIAS_SOFTMAX_CE (what softmax_ce_kernel computes, fused): labels in, the rest optional outputs
+  const float* y;          // [M][N] one-hot
+  float inv_batch;
+  float* prob;             // [M][N]
+  float* dz;               // [M][N] (p - y) * inv_batch
+  float* loss_rows;        // [M]
+  float* correct_rows;     // [M]
 };
 
 // AMODE/BMODE 0: K contiguous in memory (operand(i,k) = P[i*ld + k]); 1: K strided (P[k*ld + i]).
@@ -215,7 +223,61 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
       s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
     }
     const int gm = m0 + row;
-    if (gm < g.M) {
+    if (g.epi == EPI_BIAS_SOFTMAX_CE) {
+      // the row's (<= 32) logits sit in the 8 consecutive lanes that share `row`: butterfly over lane bits 0..2.
+      // Same definitions as softmax_ce_kernel (first maximum wins ties); every lane takes part in the shuffles.
+      const bool rv = gm < g.M;
+      float z[4];
+      float mx = -INFINITY;
+      int am = 0x7fffffff;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool cv = rv && (gn + e < g.N);
+        z[e] = cv ? (&s.x)[e] + g.bias[gn + e] : -INFINITY;
+        if (z[e] > mx) { mx = z[e]; am = gn + e; }
+      }
+#pragma unroll
+      for (int o2 = 1; o2 < 8; o2 <<= 1) {
+        const float omx = __shfl_xor(mx, o2, 64);
+        const int oam = __shfl_xor(am, o2, 64);
+        if (omx > mx || (omx == mx && oam < am)) { mx = omx; am = oam; }
+      }
+      float se = 0.0f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) se += (z[e] > -INFINITY) ? expf(z[e] - mx) : 0.0f;
+#pragma unroll
+      for (int o2 = 1; o2 < 8; o2 <<= 1) se += __shfl_xor(se, o2, 64);
+      const float lse = logf(se), inv = 1.0f / se;
+      float loss = 0.0f, ymax = -INFINITY;
+      int ay = 0x7fffffff;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (rv && gn + e < g.N) {
+          const size_t idx = (size_t)gm * g.N + gn + e;
+          const float zs = z[e] - mx;
+          const float pc = expf(zs) * inv;
+          g.C[(size_t)gm * g.ldc + gn + e] = z[e];
+          if (g.prob) g.prob[idx] = pc;
+          if (g.y) {
+            const float yc = g.y[idx];
+            if (yc != 0.0f) loss -= yc * (zs - lse);
+            if (yc > ymax) { ymax = yc; ay = gn + e; }
+            if (g.dz) g.dz[idx] = (pc - yc) * g.inv_batch;
+          }
+        }
+      }
+#pragma unroll
+      for (int o2 = 1; o2 < 8; o2 <<= 1) {
+        loss += __shfl_xor(loss, o2, 64);
+        const float oym = __shfl_xor(ymax, o2, 64);
+        const int oay = __shfl_xor(ay, o2, 64);
+        if (oym > ymax || (oym == ymax && oay < ay)) { ymax = oym; ay = oay; }
+      }
+      if (rv && tcol == 0) {
+        if (g.loss_rows) g.loss_rows[gm] = loss;
+        if (g.correct_rows) g.correct_rows[gm] = (am == ay) ? 1.0f : 0.0f;
+      }
+    } else if (gm < g.M) {
       const float v[4] = {s.x, s.y, s.z, s.w};
       float o[4];
 #pragma unroll
@@ -517,6 +579,13 @@ static int launch_gemm(int amode, int bmode, const GemmArgs& g, hipStream_t st) 
   }
   // Few output tiles and a long K (the dW GEMMs of the narrow layers, K = batch): 16 wavefronts split K so that
   // the serial chain of chunk loads per wavefront stays short.  Not for the *_STATS epilogues (never needed there).
+  if (g.epi == EPI_BIAS_SOFTMAX_CE) {  // one 32-wide column tile, 4 wavefronts: the epilogue reduces along lanes
+    if (g.N > 32) { set_error("gemm: the fused softmax epilogue needs N <= 32 (got %d)", g.N); return LIPASR_EINVAL; }
+    if (amode == 0 && bmode == 1) launch_gemm_t<0, 1, 4>(g, st);
+    else { set_error("gemm: the fused softmax epilogue is a forward (NN) epilogue"); return LIPASR_EINVAL; }
+    LP_LAUNCH_CHECK();
+    return LIPASR_OK;
+  }
   if (use_lds_gemm(g.M, g.N, g.K)) {
     const dim3 grid((g.N + 63) / 64, (g.M + 63) / 64);
     if (amode == 0 && bmode == 0) hipLaunchKernelGGL((gemm_lds_kernel<0, 0>), grid, dim3(512), 0, st, g);
@@ -970,16 +1039,28 @@ static DropArgs drop_for_layer(const lipasr_mlp* m, int l, const lipasr_dropout_
 }
 
 // inference-mode forward: fills A_l (post-ReLU, if keep_a) and H_l, logits into m->ws
+// ce_y != nullptr (and <= 32 classes): the last GEMM's epilogue also produces softmax, and (p - y) / batch at
+// m->ws + offDzLast -- the caller then skips softmax_ce_kernel.  Returns through *fused whether it did.
 static int forward_infer(lipasr_mlp* m, const float* params, const float* bnstate, const float* x, int batch,
-                         bool keep_a, float* logits_out, hipStream_t st) {
+                         bool keep_a, float* logits_out, hipStream_t st, const float* ce_y = nullptr,
+                         bool* fused = nullptr) {
   const float* hin = x;
+  if (fused) *fused = false;
   for (int l = 0; l < m->n_layers; ++l) {
     const MlpLayer& L = m->L[l];
     const bool last = (l == m->n_layers - 1);
     float* outp = last ? logits_out : (m->ws + L.offH);
+    const bool fuse = last && ce_y && L.n_out <= 32;
     GemmArgs g = gemm_args(hin, L.n_in, params + L.offW, L.n_out, outp, L.n_out, batch, L.n_out, L.n_in,
-                           last ? EPI_BIAS : EPI_BIAS_RELU_BN);
+                           last ? (fuse ? EPI_BIAS_SOFTMAX_CE : EPI_BIAS) : EPI_BIAS_RELU_BN);
     g.bias = params + L.offb;
+    if (fuse) {
+      g.y = ce_y;
+      g.inv_batch = 1.0f / (float)batch;
+      g.prob = m->ws + m->offProb;
+      g.dz = m->ws + m->offDzLast;
+      if (fused) *fused = true;
+    }
     if (!last) {
       if (L.bn) {
         g.gamma = params + L.offg;
@@ -1060,10 +1141,19 @@ int lipasr_mlp_train_fwd_bwd(lipasr_mlp_t m, const float* params, float* bnstate
     const MlpLayer& L = m->L[l];
     const bool last = (l == Lc - 1);
     float* outp = last ? (ws + m->offLogits) : (ws + L.offA);
+    const bool fuse_ce = last && C <= 32;  // softmax, loss and (p - y) / B in the last GEMM's epilogue
     GemmArgs g = gemm_args(hin, L.n_in, params + L.offW, L.n_out, outp, L.n_out, batch, L.n_out, L.n_in,
-                           last ? EPI_BIAS : (L.bn ? EPI_BIAS_RELU_STATS : EPI_BIAS_RELU));
+                           last ? (fuse_ce ? EPI_BIAS_SOFTMAX_CE : EPI_BIAS) : (L.bn ? EPI_BIAS_RELU_STATS : EPI_BIAS_RELU));
     g.bias = params + L.offb;
     g.part = part;
+    if (fuse_ce) {
+      g.y = y_onehot;
+      g.inv_batch = inv_batch;
+      g.prob = probs ? probs : (ws + m->offProb);
+      g.dz = ws + m->offDzLast;
+      g.loss_rows = loss_rows;
+      g.correct_rows = correct_rows;
+    }
     rc = launch_gemm(0, 1, g, st);
     if (rc != LIPASR_OK) return rc;
     if (!last && L.offH != L.offA) {
@@ -1086,11 +1176,13 @@ int lipasr_mlp_train_fwd_bwd(lipasr_mlp_t m, const float* params, float* bnstate
       hin = outp;
     }
   }
-  // ---- loss and gradient at the logits
-  hipLaunchKernelGGL(softmax_ce_kernel, dim3((batch + 255) / 256), dim3(256), 0, st, ws + m->offLogits, y_onehot, batch, C,
-                     inv_batch, probs ? probs : (ws + m->offProb), ws + m->offDzLast, loss_rows, correct_rows,
-                     (float*)nullptr);
-  LP_LAUNCH_CHECK();
+  // ---- loss and gradient at the logits (already done by the last GEMM's epilogue for <= 32 classes)
+  if (C > 32) {
+    hipLaunchKernelGGL(softmax_ce_kernel, dim3((batch + 255) / 256), dim3(256), 0, st, ws + m->offLogits, y_onehot, batch,
+                       C, inv_batch, probs ? probs : (ws + m->offProb), ws + m->offDzLast, loss_rows, correct_rows,
+                       (float*)nullptr);
+    LP_LAUNCH_CHECK();
+  }
 
   // ---- backward.  The dX chain runs first, layer by layer (dX GEMM fused with the dropout backward and the
   // BatchNorm column sums, then the BatchNorm/ReLU backward apply), keeping every layer's pre-activation gradient;
@@ -1174,13 +1266,16 @@ static int attack_common(lipasr_mlp_t m, const float* params, const float* bnsta
                          const float* y_onehot, int batch, float* dx, float* x_adv, const float* x0, float alpha,
                          float eps, hipStream_t st) {
   float* lg = m->ws + m->offLogits;
-  int rc = forward_infer(m, params, bnstate, x_eval, batch, true, lg, st);
+  bool fused = false;
+  int rc = forward_infer(m, params, bnstate, x_eval, batch, true, lg, st, y_onehot, &fused);
   if (rc != LIPASR_OK) return rc;
-  const int C = m->L[m->n_layers - 1].n_out;
-  hipLaunchKernelGGL(softmax_ce_kernel, dim3((batch + 255) / 256), dim3(256), 0, st, lg, y_onehot, batch, C,
-                     1.0f / (float)batch, m->ws + m->offProb, m->ws + m->offDzLast, (float*)nullptr, (float*)nullptr,
-                     (float*)nullptr);
-  LP_LAUNCH_CHECK();
+  if (!fused) {
+    const int C = m->L[m->n_layers - 1].n_out;
+    hipLaunchKernelGGL(softmax_ce_kernel, dim3((batch + 255) / 256), dim3(256), 0, st, lg, y_onehot, batch, C,
+                       1.0f / (float)batch, m->ws + m->offProb, m->ws + m->offDzLast, (float*)nullptr, (float*)nullptr,
+                       (float*)nullptr);
+    LP_LAUNCH_CHECK();
+  }
   return backward_infer(m, params, bnstate, batch, dx, x_adv, x0, alpha, eps, st);
 }
 

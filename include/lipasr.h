@@ -274,9 +274,10 @@ int lipasr_mfcc_from_22k(lipasr_handle_t h, const float* y, int batch, int n_y, 
                          const double* affine_mean, const double* affine_scale, float* out,
                          lipasr_stream_t stream);
 
-/* Per-kernel HIP-event timing of the next `max_calls` lipasr_mfcc_f32 calls, recorded on the stream the
- * kernels run on.  _end synchronises and returns the average milliseconds of {resample, stft_mel, dct}
- * (host float[3]) and the number of calls measured (host int). */
+/* Per-kernel HIP-event timing of the next `max_calls` extractions -- lipasr_mfcc_f32 calls, or
+ * lipasr_resample_f32 + lipasr_mfcc_from_22k pairs -- recorded on the stream the kernels run on.
+ * _end synchronises and returns the average milliseconds of {resample, stft_mel, dct}
+ * (host float[3]) and the number of extractions measured (host int). */
 int lipasr_mfcc_profile_begin(lipasr_handle_t h, int max_calls);
 int lipasr_mfcc_profile_end(lipasr_handle_t h, float* avg_ms3, int* n_calls);
 
