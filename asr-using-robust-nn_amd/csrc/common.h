@@ -103,4 +103,8 @@ struct Philox {
   __host__ __device__ static inline float u01(uint32_t x) { return ((x >> 8) + 1u) * (1.0f / 16777216.0f); }
 };
 
+// spectral.hip: lipasr_project_product with an optional device counter bumped by its single-workgroup kernel
+int project_product_bump(lipasr_handle_t h, float* const* Ws, const int* rows, const int* cols, int n_layers, float rho,
+                         const int* order, int n_order, float* norms_out, int* bump, lipasr_stream_t stream);
+
 }  // namespace lipasr

@@ -128,9 +128,9 @@ using namespace lipasr;
 
 extern "C" {
 
-int lipasr_mlp_adam_nonneg(lipasr_mlp_t m, float* params, const float* grads, float* adam_m, float* adam_v,
-                           int* step_dev, float lr, float beta1, float beta2, float eps, float grad_scale,
-                           lipasr_stream_t stream) {
+static int adam_launch(lipasr_mlp_t m, float* params, const float* grads, float* adam_m, float* adam_v, int* step_dev,
+                       float lr, float beta1, float beta2, float eps, float grad_scale, bool bump_step,
+                       lipasr_stream_t stream) {
   LP_CHECK_ARG(m && params && grads && adam_m && adam_v && step_dev, "lipasr_mlp_adam_nonneg: null argument");
   LP_CHECK_ARG(((reinterpret_cast<uintptr_t>(params) | reinterpret_cast<uintptr_t>(grads) |
                  reinterpret_cast<uintptr_t>(adam_m) | reinterpret_cast<uintptr_t>(adam_v)) & 15) == 0,
@@ -156,11 +156,32 @@ int lipasr_mlp_adam_nonneg(lipasr_mlp_t m, float* params, const float* grads, fl
   hipLaunchKernelGGL(adam_nonneg_kernel, dim3(blocks), dim3(256), 0, S(stream), params, grads, adam_m, adam_v, n4, segs,
                      step_dev, lr, beta1, beta2, eps, grad_scale);
   LP_LAUNCH_CHECK();
-  // a second one-thread launch: a last-workgroup ticket inside the Adam kernel measured 11 us slower (atomics
-  // from 1-2 K workgroups on one address) than this 4.6 us launch
-  hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, S(stream), step_dev);
-  LP_LAUNCH_CHECK();
+  if (bump_step) {
+    // a second one-thread launch: a last-workgroup ticket inside the Adam kernel measured 11 us slower (atomics
+    // from 1-2 K workgroups on one address) than this 4.6 us launch
+    hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, S(stream), step_dev);
+    LP_LAUNCH_CHECK();
+  }
   return LIPASR_OK;
+}
+
+int lipasr_mlp_adam_nonneg(lipasr_mlp_t m, float* params, const float* grads, float* adam_m, float* adam_v,
+                           int* step_dev, float lr, float beta1, float beta2, float eps, float grad_scale,
+                           lipasr_stream_t stream) {
+  return adam_launch(m, params, grads, adam_m, adam_v, step_dev, lr, beta1, beta2, eps, grad_scale, true, stream);
+}
+
+int lipasr_mlp_adam_project_product(lipasr_mlp_t m, float* params, const float* grads, float* adam_m, float* adam_v,
+                                    int* step_dev, float lr, float beta1, float beta2, float eps, float grad_scale,
+                                    float rho, const int* order, int n_order, float* norms_out,
+                                    lipasr_stream_t stream) {
+  int rc = adam_launch(m, params, grads, adam_m, adam_v, step_dev, lr, beta1, beta2, eps, grad_scale, false, stream);
+  if (rc != LIPASR_OK) return rc;
+  float* Ws[LIPASR_MAX_LAYERS];
+  int rows[LIPASR_MAX_LAYERS], cols[LIPASR_MAX_LAYERS];
+  const int n = layer_arrays(m, params, Ws, rows, cols);
+  // the step counter moves inside the projection's single-workgroup kernel (after Adam has read it)
+  return lipasr::project_product_bump(m->ctx, Ws, rows, cols, n, rho, order, n_order, norms_out, step_dev, stream);
 }
 
 int lipasr_sign_step(lipasr_handle_t h, float* x_adv, const float* x0, const float* g, size_t n, float alpha, float eps,

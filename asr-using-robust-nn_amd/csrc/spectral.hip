@@ -171,7 +171,8 @@ __global__ __launch_bounds__(kSigmaThreads) void product_sigma_kernel(const doub
                                                                        int R, double rho, OrderArgs oa,
                                                                        float* __restrict__ scales,
                                                                        float* __restrict__ norms_out,
-                                                                       float* __restrict__ sigma_out) {
+                                                                       float* __restrict__ sigma_out,
+                                                                       int* __restrict__ bump) {
   __shared__ double A[kMaxR * kMaxR];
   __shared__ double B[kMaxR * kMaxR];
   __shared__ double slice_sum[kSliceDoubles];
@@ -241,6 +242,7 @@ __global__ __launch_bounds__(kSigmaThreads) void product_sigma_kernel(const doub
     }
   }
   if (tid == 0) {
+    if (bump) *bump += 1;  // the optimizer's step counter, when this projection closes a fused Adam + projection step
     const double sigma = zero ? 0.0 : exp(0.5 * log_lambda);
     if (sigma_out) *sigma_out = (float)sigma;
     if (scales) {
@@ -839,6 +841,16 @@ int lipasr_project_per_layer(lipasr_handle_t h, float* const* Ws, const int* row
 
 int lipasr_project_product(lipasr_handle_t h, float* const* Ws, const int* rows, const int* cols, int n_layers,
                            float rho, const int* order, int n_order, float* norms_out, lipasr_stream_t stream) {
+  return lipasr::project_product_bump(h, Ws, rows, cols, n_layers, rho, order, n_order, norms_out, nullptr, stream);
+}
+
+}  // extern "C"
+
+// bump: optional device int incremented by the (single-workgroup) eigenvalue kernel -- lets the fused
+// Adam + projection entry point drop its one-thread step-counter launch
+int lipasr::project_product_bump(lipasr_handle_t h, float* const* Ws, const int* rows, const int* cols, int n_layers,
+                                 float rho, const int* order, int n_order, float* norms_out, int* bump,
+                                 lipasr_stream_t stream) {
   LP_CHECK_ARG(h && norms_out, "lipasr_project_product: null argument");
   int rc = check_layers("lipasr_project_product", Ws, rows, cols, n_layers, true);
   if (rc != LIPASR_OK) return rc;
@@ -858,7 +870,7 @@ int lipasr_project_product(lipasr_handle_t h, float* const* Ws, const int* rows,
   rc = launch_chain(h, Ws, rows, cols, n_layers, &cs, &n_part, S(stream));
   if (rc != LIPASR_OK) return rc;
   hipLaunchKernelGGL(product_sigma_kernel, dim3(1), dim3(kSigmaThreads), 0, S(stream), cs.gram, n_part, cols[n_layers - 1],
-                     (double)rho, oa, cs.scales, norms_out, cs.sigma);
+                     (double)rho, oa, cs.scales, norms_out, cs.sigma, bump);
   LP_LAUNCH_CHECK();
   if (n_order > 0) {
     LayerPtrs lp;
@@ -869,6 +881,8 @@ int lipasr_project_product(lipasr_handle_t h, float* const* Ws, const int* rows,
   }
   return LIPASR_OK;
 }
+
+extern "C" {
 
 int lipasr_product_norm(lipasr_handle_t h, const float* const* Ws, const int* rows, const int* cols, int n_layers,
                         float* sigma_out, lipasr_stream_t stream) {
@@ -883,7 +897,7 @@ int lipasr_product_norm(lipasr_handle_t h, const float* const* Ws, const int* ro
   oa.n_layers = n_layers;
   oa.n_order = 0;
   hipLaunchKernelGGL(product_sigma_kernel, dim3(1), dim3(kSigmaThreads), 0, S(stream), cs.gram, n_part, cols[n_layers - 1], 1.0,
-                     oa, (float*)nullptr, (float*)nullptr, sigma_out);
+                     oa, (float*)nullptr, (float*)nullptr, sigma_out, (int*)nullptr);
   LP_LAUNCH_CHECK();
   return LIPASR_OK;
 }

@@ -77,6 +77,7 @@ PROTOTYPES = {
     "lipasr_mlp_train_fwd_bwd": (i32, [c_h, c_f, c_f, c_f, c_f, i32, f32, C.POINTER(DropoutCfg), c_f, c_f, c_f, c_f, c_s]),
     "lipasr_mlp_adam_nonneg": (i32, [c_h, c_f, c_f, c_f, c_f, c_f, f32, f32, f32, f32, f32, c_s]),
     "lipasr_mlp_project_product": (i32, [c_h, c_f, f32, PI, i32, c_f, c_s]),
+    "lipasr_mlp_adam_project_product": (i32, [c_h, c_f, c_f, c_f, c_f, c_f, f32, f32, f32, f32, f32, f32, PI, i32, c_f, c_s]),
     "lipasr_mlp_project_per_layer": (i32, [c_h, c_f, f32, c_f, i32, i32, c_f, c_s]),
     "lipasr_mlp_product_norm": (i32, [c_h, c_f, c_f, c_s]),
     "lipasr_mlp_predict": (i32, [c_h, c_f, c_f, c_f, i32, c_f, c_f, c_s]),

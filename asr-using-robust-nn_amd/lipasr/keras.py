@@ -447,6 +447,13 @@ class Model:
         N.check(N.lib.lipasr_mlp_adam_nonneg(self._plan, N.ptr(self._params), N.ptr(self._grads), N.ptr(self._adam_m), N.ptr(self._adam_v),
                                              N.ptr(self._step), lr, b1, b2, eps, grad_scale, N.stream_ptr()))
 
+    def apply_adam_project_product(self, rho, order, norms_out, grad_scale=1.0):
+        """Adam + NonNeg + simple_norm_constraint (``order``: N.int_array of layer visits) as one native call."""
+        lr, b1, b2, eps = self._adam
+        N.check(N.lib.lipasr_mlp_adam_project_product(self._plan, N.ptr(self._params), N.ptr(self._grads), N.ptr(self._adam_m),
+                                                      N.ptr(self._adam_v), N.ptr(self._step), lr, b1, b2, eps, grad_scale, float(rho), order,
+                                                      len(order), N.ptr(norms_out), N.stream_ptr()))
+
     def train_on_batch(self, xb, yb, masks=None, dropout=True):
         """fwd, bwd, (data-parallel gradient all-reduce), Adam + NonNeg; returns nothing (stream-ordered)."""
         if self._dp is not None:

@@ -77,11 +77,12 @@ class TrainPipeline:
 
     def _update(self):
         m = self.model
-        m.apply_adam()
         if self.constraint == "product":
-            N.check(N.lib.lipasr_mlp_project_product(m._plan, N.ptr(m._params), self.rho, self._order, len(m._blocks), N.ptr(self.norms),
-                                                     N.stream_ptr()))
-        elif self.constraint == "per_layer":
+            # Adam + NonNeg + simple_norm_constraint in one native call (the step counter moves inside the projection)
+            m.apply_adam_project_product(self.rho, self._order, self.norms)
+            return
+        m.apply_adam()
+        if self.constraint == "per_layer":
             N.check(N.lib.lipasr_mlp_project_per_layer(m._plan, N.ptr(m._params), self.rho, N.ptr(self.v_state), 1, self.per_layer_iters,
                                                        N.ptr(self.sigmas), N.stream_ptr()))
 

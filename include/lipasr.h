@@ -203,6 +203,14 @@ int lipasr_mlp_adam_nonneg(lipasr_mlp_t m, float* params, const float* grads, fl
                            float grad_scale, lipasr_stream_t stream);
 
 /* Projections over the plan's kernels inside `params` (same semantics as the generic entry points). */
+/* One optimizer step as train_constraints.py:94-105 runs it -- Adam, NonNeg, then the
+ * simple_norm_constraint callback -- as ONE call: lipasr_mlp_adam_nonneg followed by
+ * lipasr_mlp_project_product, with the step counter advanced inside the projection's own
+ * single-workgroup kernel instead of a separate launch.  Same results as the two calls. */
+int lipasr_mlp_adam_project_product(lipasr_mlp_t m, float* params, const float* grads, float* adam_m,
+                                    float* adam_v, int* step_dev, float lr, float beta1, float beta2,
+                                    float eps, float grad_scale, float rho, const int* order,
+                                    int n_order, float* norms_out, lipasr_stream_t stream);
 int lipasr_mlp_project_product(lipasr_mlp_t m, float* params, float rho, const int* order, int n_order,
                                float* norms_out, lipasr_stream_t stream);
 int lipasr_mlp_project_per_layer(lipasr_mlp_t m, float* params, float rho, float* v_state, int warm,

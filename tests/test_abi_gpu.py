@@ -83,3 +83,33 @@ def test_timer_and_graph_replay(cuda):
     assert seq[-1][-1] < seq[0][0]
     N.check(N.lib.lipasr_graph_destroy(h.h, gid.value))
     assert N.lib.lipasr_graph_launch(h.h, gid.value, N.stream_ptr()) == N.EINVAL
+
+
+def test_adam_project_product_equals_the_two_calls(cuda):
+    """lipasr_mlp_adam_project_product == lipasr_mlp_adam_nonneg then lipasr_mlp_project_product, bit for bit,
+    including the step counter (advanced inside the projection's kernel instead of its own launch)."""
+    import lipasr._native as N
+    from helpers import build_model
+    from oracle import mlp_ref as P
+
+    spec = P.vd_constrained_spec()
+    rng = np.random.default_rng(0)
+    x = torch.as_tensor(rng.standard_normal((96, 880)).astype(np.float32)).cuda()
+    y = torch.as_tensor(P.to_categorical(rng.integers(0, 10, 96), 10).astype(np.float32)).cuda()
+    results = []
+    for fused in (False, True):
+        m = build_model(spec, max_batch=128, seed=3)
+        norms = torch.zeros(7, device="cuda")
+        order = N.int_array(list(range(6)))
+        for _ in range(3):
+            m.train_fwd_bwd(x, y, dropout=False)
+            if fused:
+                m.apply_adam_project_product(0.1, order, norms)
+            else:
+                m.apply_adam()
+                N.check(N.lib.lipasr_mlp_project_product(m._plan, N.ptr(m._params), 0.1, order, 6, N.ptr(norms), N.stream_ptr()))
+        torch.cuda.synchronize()
+        results.append((m._params.clone(), norms.clone(), int(m._step.item())))
+    assert results[0][2] == results[1][2] == 3
+    assert torch.equal(results[0][0], results[1][0])
+    assert torch.equal(results[0][1], results[1][1])
