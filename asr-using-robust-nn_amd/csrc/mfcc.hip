@@ -237,6 +237,104 @@ __global__ __launch_bounds__(64 * kRsWaves) void resample_mfma_kernel(const floa
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// stage 1, persistent MFMA form.  Same contraction as resample_mfma_kernel, scheduled for the whole chip:
+//   * one workgroup per (32-clip tile, q-range): 32 x 8 = 256 workgroups for 1024 clips, one per CU, each walking
+//     6-7 consecutive q-blocks (the one-q-block kernel runs 1600 workgroups in 4 rounds on 512 slots, 3.1 rounds of work);
+//   * one wavefront per phase tile (14 wavefronts): its 76 tap fragments are loaded ONCE and stay in registers for the
+//     whole q-range (they were re-read from L2 for every q-block and clip tile: 436 MB per 1024 clips);
+//   * the input window of the next q-block travels global -> registers while the current one feeds the MFMA chain,
+//     then registers -> the other LDS buffer (2 x 61.6 kB), one barrier per q-block.
+// ---------------------------------------------------------------------------------------------
+constexpr int kRpMaxWaves = 16;
+
+__global__ __launch_bounds__(64 * kRpMaxWaves) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void resample_persist_kernel(const float* __restrict__ x, int n_samp, int batch, float* __restrict__ y, int n_valid, int n_y,
+                             int up, int down, int left, int nq, const float* __restrict__ Hband,
+                             const int* __restrict__ lo) {
+  extern __shared__ __attribute__((aligned(16))) float xs2[];  // [2][32][kRsStride]
+  const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // = phase tile
+  const int li = lane & 31, h = lane >> 5;
+  const int n_ranges = gridDim.x;
+  const int q_begin = (int)(((long)blockIdx.x * nq) / n_ranges), q_end = (int)(((long)(blockIdx.x + 1) * nq) / n_ranges);
+  const int u0 = blockIdx.y * 32;
+  constexpr int kVecPerRow = (kRsStride - 1) / 4;   // 120 float4 = 480 floats per row
+  constexpr int kFillMax = 5;                        // float4 per thread per window: 3840 over >= 768 threads
+  // tap fragments of this wavefront's phase tile: loaded once
+  float bq[kRsBand / 2];
+  {
+    const float* hb = Hband + (size_t)wave * kRsBand * 32 + h * 32 + li;
+#pragma unroll
+    for (int s = 0; s < kRsBand / 2; ++s) bq[s] = hb[s * 64];
+  }
+  const int lo_r = lo[wave];
+  float4 stage[kFillMax];
+  // (the thread index is made opaque in both helpers so that their per-slot addresses are recomputed where they are
+  // used instead of living in 15-20 registers across the MFMA chain -- the fragments need those registers)
+  auto fetch = [&](int q) {
+    const int base = down * q - left;
+    int tq = tid;
+    asm volatile("" : "+v"(tq));
+#pragma unroll
+    for (int j = 0; j < kFillMax; ++j) {
+      const int f = tq + j * nthreads;
+      const int i = f / kVecPerRow, v = f - i * kVecPerRow;
+      const int u = u0 + i, n = base + 4 * v;
+      stage[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (f < 32 * kVecPerRow && u < batch && n >= 0 && n + 3 < n_samp)
+        stage[j] = *reinterpret_cast<const float4*>(x + (size_t)u * n_samp + n);
+    }
+  };
+  auto deposit = [&](float* xs) {
+    int tq = tid;
+    asm volatile("" : "+v"(tq));
+#pragma unroll
+    for (int j = 0; j < kFillMax; ++j) {
+      const int f = tq + j * nthreads;
+      if (f < 32 * kVecPerRow) {
+        const int i = f / kVecPerRow, v = f - i * kVecPerRow;
+        float* d = xs + i * kRsStride + 4 * v;
+        d[0] = stage[j].x; d[1] = stage[j].y; d[2] = stage[j].z; d[3] = stage[j].w;
+      }
+    }
+    if (tid < 32) xs[tid * kRsStride + kRsStride - 1] = 0.0f;
+  };
+  if (q_begin < q_end) {
+    fetch(q_begin);
+    deposit(xs2);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int q = q_begin; q < q_end; ++q) {
+    const bool more = q + 1 < q_end;
+    if (more) fetch(q + 1);
+    const float* xa = xs2 + cur * 32 * kRsStride + li * kRsStride + lo_r + 1 + h;
+    rs_f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < kRsBand / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[2 * s], bq[s], acc, 0, 0, 0);
+    const int pp = 32 * wave + li;
+    const int t = q * up + pp;
+    if (pp < up && t < n_y) {
+      float* yb = y + (size_t)u0 * n_y;
+      int off = 4 * h * n_y + t;
+      asm volatile("" : "+v"(off));  // formed here: sixteen hoisted 64-bit row addresses would cost the fragment registers
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2);
+        if (u0 + row + 4 * h < batch) yb[off + row * n_y] = t < n_valid ? acc[e] : 0.0f;
+      }
+    }
+    if (more) deposit(xs2 + (cur ^ 1) * 32 * kRsStride);  // the other buffer: nobody reads it during this q-block
+    // LDS-only barrier: __syncthreads() would also wait for this q-block's output stores to reach memory
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    cur ^= 1;
+  }
+}
+
 __global__ __launch_bounds__(256) void copy_pad_kernel(const float* __restrict__ x, int n_samp, float* __restrict__ y,
                                                         int n_y) {
   const int u = blockIdx.y;
@@ -926,7 +1024,25 @@ static int launch_resample(const MfccPlan* p, const float* wav, int batch, float
     return LIPASR_OK;
   }
   const int nq = (p->n_y + p->up - 1) / p->up;
-  if (p->d_hband && !(p->stage_mask & 4)) {
+  const bool vec4 = ((p->n_samp & 3) == 0) && ((p->down & 3) == 0) && ((reinterpret_cast<uintptr_t>(wav) & 15) == 0);
+  const int n_waves = p->n_ptiles;
+  if (p->d_hband && !(p->stage_mask & (4 | 64)) && vec4 && n_waves >= 8 && n_waves <= kRpMaxWaves &&
+      32 * ((kRsStride - 1) / 4) <= 5 * 64 * n_waves) {
+    // persistent form: one workgroup per CU-sized share of the work
+    const size_t lds = (size_t)2 * 32 * kRsStride * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+      LP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(resample_persist_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_set = true;
+    }
+    const int tiles = (batch + 31) / 32;
+    int n_ranges = 256 / (tiles > 0 ? tiles : 1);  // aim at one workgroup per CU
+    if (n_ranges < 1) n_ranges = 1;
+    if (n_ranges > nq) n_ranges = nq;
+    hipLaunchKernelGGL(resample_persist_kernel, dim3(n_ranges, tiles), dim3(64 * n_waves), lds, st, wav, p->n_samp, batch, y,
+                       p->n_valid, p->n_y, p->up, p->down, p->left, nq, p->d_hband, p->d_lo);
+  } else if (p->d_hband && !(p->stage_mask & 4)) {
     const size_t lds = (size_t)32 * kRsStride * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
