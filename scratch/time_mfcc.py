@@ -9,7 +9,7 @@ wt=torch.as_tensor(w).cuda()
 ex=MfccExtractor(16000,16000,B)
 out=torch.empty(B,880,device='cuda')
 s=torch.cuda.Stream()
-for mask in (0,):
+for mask in [int(a) for a in sys.argv[2:]] or [0]:
     N.check(N.lib.lipasr_debug_set(ex.h.h,0,mask))
     with torch.cuda.stream(s):
         for _ in range(3): ex(wt,44,out=out)
