@@ -218,7 +218,7 @@ def main():
     traffic = None
     try:
         with open(os.path.join(ROOT, "profiles", "r02_mfcc_pmc.json")) as f:
-            traffic = round(json.load(f)["after_xcd_mapping"]["stage_bytes_per_utt"] * batch)
+            traffic = round(json.load(f)["end_of_round"]["stage_bytes_per_utt"] * batch)
     except Exception:
         pass
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
