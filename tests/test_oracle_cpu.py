@@ -287,3 +287,123 @@ def test_noise_models_statistics():
     noisy = A.add_white_noise_with_snr(sig, 10.0, rng)
     snr = 10 * np.log10(np.mean(sig ** 2) / np.mean((noisy - sig) ** 2))
     assert abs(snr - 10.0) < 0.1
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Independent implementations that ARE installed here (the reference itself is not importable): sklearn's own
+# StandardScaler (the class the reference calls, train_constraints.py:28-35), torch.stft and torch autograd.
+# They pin the restatement's arithmetic, not the reference's pinned versions: DESIGN.md section 4.
+def test_scaler_oracle_equals_sklearn():
+    from sklearn.preprocessing import StandardScaler
+
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((500, 37)) * rng.uniform(0.01, 40, 37) + rng.uniform(-100, 100, 37)
+    x[:, 5] = 7.5           # constant column: sklearn keeps scale 1
+    x[:, 11] = 3.0 + 4.4e-16 * rng.integers(0, 2, 500)  # numerically constant: below the two-pass error bound
+    sk = StandardScaler().fit(x)
+    mean, scale = P.standard_scaler_fit(x)
+    np.testing.assert_allclose(mean, sk.mean_, rtol=0, atol=1e-12)
+    assert sk.scale_[5] == 1.0 and sk.scale_[11] == 1.0
+    np.testing.assert_allclose(scale, sk.scale_, rtol=1e-12, atol=0)
+    np.testing.assert_allclose((x - mean) / scale, sk.transform(x), atol=1e-10)
+
+
+@pytest.mark.parametrize("n_fft,hop", [(2048, 512), (441, 220)])
+def test_stft_oracle_equals_torch_stft(n_fft, hop):
+    import torch
+
+    rng = np.random.default_rng(n_fft)
+    y = (0.3 * rng.standard_normal(22050)).astype(np.float64)
+    S = M.power_spectrogram(y, np.float64, n_fft, hop)
+    win = torch.hann_window(n_fft, periodic=True, dtype=torch.float64)
+    Z = torch.stft(torch.as_tensor(y), n_fft=n_fft, hop_length=hop, win_length=n_fft, window=win, center=True,
+                   pad_mode="reflect", return_complex=True)
+    ref = (Z.abs() ** 2).numpy()
+    assert S.shape == ref.shape == (1 + n_fft // 2, 1 + 22050 // hop)
+    np.testing.assert_allclose(S, ref, rtol=1e-9, atol=1e-12 * ref.max())
+
+
+def _torch_forward(spec, p, x, training, masks=None):
+    """The Keras semantics of A3 written with torch ops (double), for autograd to differentiate."""
+    import torch
+
+    h = x
+    stats = []
+    for l, s in enumerate(spec):
+        z = h @ p["W"][l] + p["b"][l]
+        if l == len(spec) - 1:
+            return z, stats
+        a = torch.relu(z)
+        if s.bn:
+            if training:
+                mu, var = a.mean(dim=0), a.var(dim=0, unbiased=False)
+            else:
+                mu, var = p["mm"][l], p["mv"][l]
+            stats.append((mu, var))
+            a = (a - mu) / torch.sqrt(var + P.BN_EPS) * p["g"][l] + p["be"][l]
+        if masks is not None and masks[l] is not None:
+            a = a * masks[l]
+        h = a
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_mlp_oracle_gradients_equal_torch_autograd(training):
+    import torch
+
+    spec = [P.LayerSpec(13, 11, True, 0.25, True), P.LayerSpec(11, 7, True, 0.0, True), P.LayerSpec(7, 5, False, 0.0, True)]
+    p = P.init_params(spec, seed=4, dtype=np.float64)
+    rng = np.random.default_rng(9)
+    for l in range(2):
+        p.gamma[l] = 1 + 0.3 * rng.standard_normal(spec[l].n_out)
+        p.beta[l] = 0.2 * rng.standard_normal(spec[l].n_out)
+        p.mov_mean[l] = 0.1 * rng.standard_normal(spec[l].n_out)
+        p.mov_var[l] = rng.uniform(0.5, 2.0, spec[l].n_out)
+    x = rng.standard_normal((17, 13))
+    y = P.to_categorical(rng.integers(0, 5, 17), 5).astype(np.float64)
+    masks = [((rng.uniform(size=(17, 11)) > 0.25) / 0.75) if training else None, None, None]
+    T = lambda a: None if a is None else torch.tensor(a, dtype=torch.float64, requires_grad=True)
+    tp = {"W": [T(w) for w in p.W], "b": [T(b) for b in p.b], "g": [T(g) for g in p.gamma], "be": [T(b) for b in p.beta],
+          "mm": [None if a is None else torch.tensor(a) for a in p.mov_mean], "mv": [None if a is None else torch.tensor(a) for a in p.mov_var]}
+    xt = torch.tensor(x, requires_grad=True)
+    tm = None if not training else [None if k is None else torch.tensor(k) for k in masks]
+    logits, _ = _torch_forward(spec, tp, xt, training, tm)
+    loss = -(torch.tensor(y) * torch.log_softmax(logits, dim=1)).sum(dim=1).mean()
+    loss.backward()
+    got = P.forward_backward(spec, p, x, y, masks=masks if training else None, training=training, need_dx=True)
+    assert abs(got["loss"] - float(loss.detach())) < 1e-12
+    np.testing.assert_allclose(got["logits"], logits.detach().numpy(), atol=1e-12)
+    for l in range(3):
+        np.testing.assert_allclose(got["dW"][l], tp["W"][l].grad.numpy(), atol=1e-12)
+        np.testing.assert_allclose(got["db"][l], tp["b"][l].grad.numpy(), atol=1e-12)
+        if spec[l].bn:
+            np.testing.assert_allclose(got["dgamma"][l], tp["g"][l].grad.numpy(), atol=1e-12)
+            np.testing.assert_allclose(got["dbeta"][l], tp["be"][l].grad.numpy(), atol=1e-12)
+    np.testing.assert_allclose(got["dx"], xt.grad.numpy(), atol=1e-12)
+    if not training:
+        # the vector-Jacobian product behind class_gradient / JSMA / C&W, at the softmax outputs and at the logits
+        v = rng.standard_normal((17, 5))
+        for on_logits in (False, True):
+            xt2 = torch.tensor(x, requires_grad=True)
+            lg, _ = _torch_forward(spec, tp, xt2, False)
+            out = lg if on_logits else torch.softmax(lg, dim=1)
+            (out * torch.tensor(v)).sum().backward()
+            dx, prob = P.output_vjp_infer(spec, p, x, v, on_logits=on_logits)
+            np.testing.assert_allclose(dx, xt2.grad.numpy(), atol=1e-12)
+            np.testing.assert_allclose(prob, torch.softmax(lg, dim=1).detach().numpy(), atol=1e-14)
+
+
+def test_adam_oracle_equals_torch_adam_up_to_epsilon_placement():
+    """Keras-form Adam differs from torch.optim.Adam only in where epsilon sits; with eps -> 0 both agree."""
+    import torch
+
+    rng = np.random.default_rng(3)
+    w = rng.standard_normal((10, 5))
+    m, v = np.zeros_like(w), np.zeros_like(w)
+    wt = torch.tensor(w.copy(), requires_grad=True)
+    opt = torch.optim.Adam([wt], lr=1e-3, betas=(0.9, 0.999), eps=1e-30)
+    for t in range(1, 6):
+        g = rng.standard_normal((10, 5))
+        P.adam_update(w, g, m, v, t, eps=1e-30)
+        wt.grad = torch.tensor(g)
+        opt.step()
+    np.testing.assert_allclose(w, wt.detach().numpy(), rtol=1e-10, atol=1e-13)
