@@ -18,9 +18,15 @@ NOT done: a stand-in for a library the image lacks is not a reference run.  So:
   known answers (sigma_max == rho^(1/m) after ``norm_constraint``; the product-norm law
   n_k = n0^((5/6)^k) rho^(1-(5/6)^k) for ``simple_norm_constraint``) and LAPACK SVD.
 * ``mfcc_ref``   -- librosa/resampy/scipy.fftpack restated from their published algorithm
-  (early-2022 defaults); checked by analytic signals (tone resampling, filter-bank shape).
-* ``mlp_ref``    -- TensorFlow/Keras restated; checked by finite-difference gradients.
-* ``attacks_ref``-- ART restated.
+  (early-2022 defaults); checked by analytic signals (tone resampling, filter-bank shape), SciPy's
+  Hann / DCT, and ``torch.stft`` for both window shapes (2048/512 and the Speaker-recognition 441/220).
+* ``mlp_ref``    -- TensorFlow/Keras restated; checked by finite-difference gradients, by torch autograd
+  for every gradient it produces (training and inference mode, the output VJP), by scikit-learn's own
+  ``StandardScaler`` and by ``torch.optim.Adam`` in the eps -> 0 limit.
+* ``attacks_ref``-- ART restated (FGSM, PGD, JSMA, Carlini-Wagner L2 / Linf) from its published algorithms.
+
+These are independent implementations installed in the image, not the reference's pinned versions:
+they check the restatement's arithmetic, the status stays PARITY UNPINNED.
 
 The known-answer checks live in tests/test_oracle_cpu.py.  ``tests/golden/*.npz`` are produced by
 THIS oracle (tests/golden/make_golden.py), not by the reference; they are regression vectors that
