@@ -196,3 +196,41 @@ def test_training_accuracy_parity(cuda):
     load_params(md, pc)
     hd = md.fit(ds, epochs=5, verbose=0, callbacks=[simple_norm_constraint(0.1, [])])
     assert np.isfinite(hd["loss"]).all() and abs(hd["loss"][-1] - losses[-1]) < 0.15 * losses[-1] + 0.05
+
+
+@pytest.mark.parametrize("seed", [3, 4, 5])
+def test_accuracy_parity_three_seeds(cuda, seed):
+    """top-1 accuracy within +-0.5 pt, over three seeds (data, split and initialisation all change with the
+    seed).  (i) dropout off: GPU and oracle run the same arithmetic, so the accuracies must agree to the half point;
+    (ii) the reference's dropout (0.4 on every hidden block): the GPU draws Philox masks, the oracle NumPy masks --
+    different streams, as TensorFlow's would be -- and both must land in the same place."""
+    from lipasr.attacks import standardize_dataset
+    from lipasr.extract_features_construct_dataset import mfcc
+    from lipasr.keras import Dataset
+    from lipasr.synth import synth_clips
+
+    waves, labels = synth_clips(1536, seed=100 + seed)
+    feats = np.concatenate([mfcc(waves[s:s + 512]).cpu().numpy() for s in range(0, 1536, 512)]).astype(np.float64)
+    tr, _, te = standardize_dataset(feats[:1024], feats[1024:1025], feats[1024:])
+    ytr, yte = P.to_categorical(labels[:1024], 10), labels[1024:]
+    ds = Dataset.from_tensor_slices((tr, ytr)).batch(128)
+    accs = {}
+    for drop in (0.0, 0.4):
+        spec = [P.LayerSpec(s.n_in, s.n_out, s.bn, drop if i < 5 else 0.0, False) for i, s in enumerate(P.vd_unconstrained_spec())]
+        p0 = P.init_params(spec, seed=seed, dtype=np.float32)
+        m = build_model(spec, max_batch=128, seed=seed)
+        load_params(m, p0)
+        m.fit(ds, epochs=12, verbose=0)
+        acc_gpu = float(np.mean(m.predict(te).argmax(1) == yte))
+        p64, st = p0.astype(np.float64), P.AdamState()
+        rng = np.random.default_rng(seed)
+        for _ in range(12):
+            for s in range(0, 1024, 128):
+                masks = None
+                if drop > 0:
+                    masks = [((rng.uniform(size=(128, sp.n_out)) > sp.dropout) / (1 - sp.dropout)) if sp.dropout > 0 else None for sp in spec]
+                P.train_step(spec, p64, st, tr[s:s + 128], ytr[s:s + 128].astype(np.float64), masks=masks)
+        acc_ref = float(np.mean(P.forward_infer(spec, p64, te).argmax(1) == yte))
+        accs[drop] = (acc_gpu, acc_ref)
+    assert abs(accs[0.0][0] - accs[0.0][1]) <= 0.005, accs
+    assert min(accs[0.4]) > 0.9 and abs(accs[0.4][0] - accs[0.4][1]) <= 0.02, accs  # independent mask streams: 512 test clips, 1 clip = 0.2 pt
