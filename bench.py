@@ -23,6 +23,9 @@ import os
 import sys
 import time
 
+# this pool's host driver only supports dmabuf IPC: RCCL needs it (harmless when already exported)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for _p in (ROOT, os.path.join(ROOT, "asr-using-robust-nn_amd")):
     if _p not in sys.path:
