@@ -286,6 +286,35 @@ class ModelCheckpoint(Callback):
         self.model.save(self.filepath)
 
 
+class TensorBoard(Callback):
+    """tensorflow.keras.callbacks.TensorBoard(log_dir=) as train_constraints.py:45-48,98 uses it: a passive logger of
+    the per-epoch scalars.  TensorBoard's event files are TensorFlow protobuf records (not writable without
+    tensorflow/tensorboard); the same scalars go to ``<log_dir>/scalars.jsonl``, one JSON object per epoch."""
+
+    def __init__(self, log_dir="logs", **_ignored):
+        super().__init__()
+        self.log_dir = str(log_dir)
+        self._fh = None
+
+    def on_train_begin(self, logs=None):
+        import os
+
+        os.makedirs(self.log_dir, exist_ok=True)
+        self._fh = open(os.path.join(self.log_dir, "scalars.jsonl"), "a")
+
+    def on_epoch_end(self, epoch, logs=None):
+        import json
+
+        if self._fh is not None:
+            self._fh.write(json.dumps({"epoch": int(epoch), **{k: float(v) for k, v in (logs or {}).items()}}) + "\n")
+            self._fh.flush()
+
+    def on_train_end(self, logs=None):
+        if self._fh is not None:
+            self._fh.close()
+            self._fh = None
+
+
 # ------------------------------------------------------------------------------------------------
 class Model:
     def __init__(self, inputs, outputs, device=None, seed=0, max_batch=1024):
@@ -577,6 +606,35 @@ class Model:
         for layer in self.layers:
             out += layer.get_weights()
         return out
+
+    def set_weights(self, weights):
+        """Keras Model.set_weights: the flat list get_weights() returns, layer by layer."""
+        weights = list(weights)
+        i = 0
+        for layer in self.layers:
+            n = len(layer.get_weights())
+            if n:
+                layer.set_weights(weights[i:i + n])
+                i += n
+        if i != len(weights):
+            raise ValueError(f"set_weights: got {len(weights)} arrays, the model holds {i}")
+
+    def save_weights(self, path):
+        """Weights only (train_constraints.py:96's commented ``load_weights`` counterpart): the trainable and
+        BatchNorm state, no optimizer moments."""
+        d = os.path.dirname(path)
+        if d:
+            os.makedirs(d, exist_ok=True)
+        torch.save({"config": self._config(), "weights": [np.asarray(w) for w in self.get_weights()]}, path)
+
+    def load_weights(self, path):
+        blob = torch.load(path, map_location="cpu", weights_only=False)
+        if "weights" in blob:
+            self.set_weights(blob["weights"])
+        else:  # a full Model.save archive: take the parameters, leave this model's optimizer state alone
+            sd = blob["state"]
+            self._params.copy_(sd["params"].to(self._device))
+            self._bnstate.copy_(sd["bnstate"].to(self._device))
 
 
 def model_from_config(cfg, **kw):

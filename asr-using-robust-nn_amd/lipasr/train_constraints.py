@@ -14,8 +14,16 @@ from .Constraints import customConstraint, norm_constraint, norm_constraint_FIST
 from .attacks import standardize_dataset
 from .extract_features_construct_dataset import get_lipschitz_constrained, get_norms, mfcc
 from .keras import (BatchNormalization, Callback, CategoricalCrossentropy, Dataset, Dense, Dropout, EarlyStopping, Input, Model,
-                    ModelCheckpoint, NonNeg, load_model, to_categorical)
+                    ModelCheckpoint, NonNeg, TensorBoard, load_model, to_categorical)
 from .synth import synth_clips_fast
+
+
+def tensorboard_callback():
+    """train_constraints.py:45-48."""
+    import datetime
+
+    logdir = "logs/log_constrained" + datetime.datetime.now().strftime("%Y%m%d-%H%M%S")
+    return TensorBoard(log_dir=logdir)
 
 
 class lip_stats_callback(Callback):

@@ -221,3 +221,37 @@ def test_layer_protocol_and_checkpoint(cuda, tmp_path):
     y = P.to_categorical(np.arange(40) % 10, 10)
     loss, acc = m.evaluate(x, y)
     assert np.isfinite(loss) and 0 <= acc <= 1
+
+
+def test_weight_io_and_tensorboard_callback(cuda, tmp_path):
+    """Model.save_weights / load_weights / set_weights (train_constraints.py:96) and the TensorBoard callback slot
+    (train_constraints.py:45-48,98): scalars land in <log_dir>/scalars.jsonl."""
+    import json
+
+    from lipasr import keras as K
+
+    spec = [P.LayerSpec(12, 8, True, 0.0, True), P.LayerSpec(8, 4, False, 0.0, True)]
+    m = build_model(spec, max_batch=32, seed=1)
+    m2 = build_model(spec, max_batch=32, seed=2)
+    x = np.random.default_rng(0).standard_normal((20, 12)).astype(np.float32)
+    assert not np.array_equal(m.predict(x), m2.predict(x))
+    path = str(tmp_path / "w" / "weights.pt")
+    m.save_weights(path)
+    m2.load_weights(path)
+    np.testing.assert_array_equal(m.predict(x), m2.predict(x))
+    m3 = build_model(spec, max_batch=32, seed=3)
+    m3.set_weights(m.get_weights())
+    np.testing.assert_array_equal(m.predict(x), m3.predict(x))
+    with pytest.raises(ValueError):
+        m3.set_weights(m.get_weights()[:-1])
+    full = str(tmp_path / "full.pt")
+    m.save(full)
+    m4 = build_model(spec, max_batch=32, seed=4)
+    m4.load_weights(full)
+    np.testing.assert_array_equal(m.predict(x), m4.predict(x))
+    # TensorBoard slot
+    y = P.to_categorical(np.arange(20) % 4, 4)
+    tb = K.TensorBoard(log_dir=str(tmp_path / "logs"))
+    m.fit(K.Dataset.from_tensor_slices((x, y)).batch(10), epochs=3, verbose=0, callbacks=[tb])
+    lines = [json.loads(l) for l in open(tmp_path / "logs" / "scalars.jsonl")]
+    assert [l["epoch"] for l in lines] == [0, 1, 2] and all("loss" in l for l in lines)
