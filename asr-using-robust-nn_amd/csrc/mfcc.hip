@@ -1150,7 +1150,9 @@ int lipasr_mfcc_plan_ex(lipasr_handle_t h, int sr_in, int n_samp, int batch_max,
   if (p->n_y < 2) { delete p; set_error("lipasr_mfcc_plan: clip too short after resampling"); return LIPASR_EINVAL; }
   p->n_fft = n_fft; p->hop = hop; p->dft = dft;
   p->n_frames = 1 + p->n_y / hop;
-  if (p->n_y <= n_fft / 2) { delete p; set_error("lipasr_mfcc_plan: clip shorter than the reflect padding"); return LIPASR_EINVAL; }
+  // the FFT path reflects repeatedly like np.pad (any clip of >= 2 samples); the short-window path's pad kernel
+  // reflects once, which needs the clip to be longer than the padding
+  if (dft && p->n_y <= n_fft / 2) { delete p; set_error("lipasr_mfcc_plan_ex: clip shorter than the reflect padding"); return LIPASR_EINVAL; }
   int rc = LIPASR_OK;
   if (!p->identity) {
     Polyphase pp = build_polyphase(sr_in, kSr);

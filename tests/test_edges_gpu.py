@@ -1,0 +1,97 @@
+"""Edge cases on the GPU path: the smallest and the raggedest inputs each entry point accepts, against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import build_model, dev, grads_of, load_params, rel_err
+from oracle import attacks_ref as A
+from oracle import mfcc_ref as M
+from oracle import mlp_ref as P
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n_samp", [2, 37, 512, 1487, 16001])
+def test_mfcc_very_short_and_odd_clips(cuda, n_samp):
+    """Clips shorter than the 1024-sample reflect padding (np.pad reflects repeatedly), odd lengths (unaligned rows:
+    the float4 paths must not be taken) and one sample over a second."""
+    from lipasr.extract_features_construct_dataset import mfcc
+
+    rng = np.random.default_rng(n_samp)
+    x = (0.2 * rng.standard_normal((3, n_samp))).astype(np.float32)
+    got = mfcc(x).cpu().numpy()
+    ref = M.compute_mfcc_batch(x)
+    assert got.shape == ref.shape == (3, 880)
+    assert np.abs(got - ref).max() < 2e-2, np.abs(got - ref).max()
+
+
+def test_mfcc_single_clip_and_full_plan(cuda):
+    from lipasr.extract_features_construct_dataset import MfccExtractor
+    from lipasr.synth import synth_clips
+
+    waves, _ = synth_clips(33, seed=5)
+    ex = MfccExtractor(16000, 16000, 33)
+    full = ex(dev(waves)).cpu().numpy()                 # batch == batch_max, one clip past a 32-clip tile
+    one = ex(dev(waves[32:33])).cpu().numpy()           # batch == 1
+    assert np.array_equal(full[32:33], one)             # a clip's features do not depend on its neighbours
+    assert np.abs(full - M.compute_mfcc_batch(waves)).max() < 2e-2
+    with pytest.raises(ValueError):
+        ex(dev(np.concatenate([waves, waves[:1]])))     # one more than the plan holds
+
+
+@pytest.mark.parametrize("batch", [1, 2, 31, 33])
+def test_classifier_tiny_and_ragged_batches(cuda, batch):
+    """batch 1 makes every BatchNorm variance exactly 0 (rstd = 1/sqrt(eps)); 31 / 33 straddle the 32-row tiles."""
+    spec = P.vd_constrained_spec()
+    p = P.init_params(spec, seed=2, dtype=np.float32, nonneg_init=True)
+    m = build_model(spec, max_batch=64)
+    load_params(m, p)
+    rng = np.random.default_rng(batch)
+    x = rng.standard_normal((batch, 880)).astype(np.float32)
+    y = P.to_categorical(rng.integers(0, 10, batch), 10)
+    ref_logits = P.forward_infer(spec, p.astype(np.float64), x.astype(np.float64), return_logits=True)
+    got_logits = m.predict_device(dev(x), logits=True).cpu().numpy()
+    assert np.abs(got_logits - ref_logits).max() <= 1e-3 * max(np.abs(ref_logits).max(), 1e-6)
+    m.train_fwd_bwd(dev(x), dev(y), dropout=False)
+    ref = P.forward_backward(spec, p.astype(np.float64), x.astype(np.float64), y.astype(np.float64), masks=None, training=True)
+    got = grads_of(m, spec)
+    assert abs(float(m._loss_rows[:batch].mean()) - ref["loss"]) < 1e-4 * max(1.0, abs(ref["loss"]))
+    for l in range(6):
+        # with batch 1 the BatchNorm backward cancels to exactly 0 in exact arithmetic; compare on an absolute scale
+        scale = max(np.abs(ref["dW"][l]).max(), 1e-4)
+        assert np.abs(got["dW"][l] - ref["dW"][l]).max() <= 2e-3 * scale, l
+
+
+def test_attacks_on_ragged_batches(cuda):
+    from lipasr.attacks import FastGradientMethod, ProjectedGradientDescent, TensorFlowV2Classifier
+
+    spec = P.vd_constrained_spec()
+    p = P.init_params(spec, seed=6, dtype=np.float32)
+    m = build_model(spec, max_batch=64)
+    load_params(m, p)
+    clf = TensorFlowV2Classifier(model=m, nb_classes=10, input_shape=(880,))
+    x = np.random.default_rng(1).standard_normal((45, 880)).astype(np.float32)   # 32 + 13
+    adv = FastGradientMethod(estimator=clf, eps=0.2).generate(x=x)
+    assert np.allclose(np.abs(adv - x).max(), 0.2, atol=1e-6)
+    p64 = p.astype(np.float64)
+    want = A.fgsm(spec, p64, x.astype(np.float64), 0.2)
+    assert np.mean(np.sign(adv - x) == np.sign(want - x)) > 0.999
+    one = ProjectedGradientDescent(estimator=clf, eps=0.3, max_iter=3).generate(x=x[:1])   # a single sample
+    assert one.shape == (1, 880) and np.abs(one - x[:1]).max() <= 0.3 + 1e-6
+
+
+def test_projection_on_degenerate_stacks(cuda):
+    """One layer, one class, and an all-zero kernel (product norm 0: the reference divides by eps = 2.2e-16)."""
+    from lipasr.Constraints import simple_norm_constraint
+    from oracle import constraints_ref as R
+    from test_spectral_gpu import FakeModel
+
+    for ws in ([np.abs(np.random.default_rng(0).standard_normal((7, 3))).astype(np.float32)],
+               [np.abs(np.random.default_rng(1).standard_normal((9, 5))).astype(np.float32), np.abs(np.random.default_rng(2).standard_normal((5, 1))).astype(np.float32)]):
+        model = FakeModel([w.copy() for w in ws])
+        cb = simple_norm_constraint(rho=0.7, affected_layers_indices=[])
+        cb.set_model(model)
+        cb.on_batch_end(0)
+        want, _ = R.simple_norm_constraint_pass(ws, 0.7, [])
+        for l, r in zip([l for l in model.layers if "dense" in l.name], want):
+            assert rel_err(l.w, r) < 2e-5
