@@ -95,3 +95,52 @@ def test_projection_on_degenerate_stacks(cuda):
         want, _ = R.simple_norm_constraint_pass(ws, 0.7, [])
         for l, r in zip([l for l in model.layers if "dense" in l.name], want):
             assert rel_err(l.w, r) < 2e-5
+
+
+@pytest.mark.parametrize("L", [1, 45, 100, 200])
+def test_mfcc_long_utterance_lengths_with_affine(cuda, L):
+    """utterance_length above the 44 frames a 1-s clip has (zero padding, several DCT frame chunks) with the fused
+    (x - mean) / scale, which also applies to the padded zeros (StandardScaler sees them as features)."""
+    from lipasr.extract_features_construct_dataset import MfccExtractor
+    from lipasr.synth import synth_clips
+
+    waves, _ = synth_clips(5, seed=9)
+    rng = np.random.default_rng(L)
+    mean = rng.standard_normal(20 * L) * 10
+    scale = rng.uniform(0.5, 20, 20 * L)
+    ex = MfccExtractor(16000, 16000, 8)
+    got = ex(dev(waves), L, torch.as_tensor(mean).cuda(), torch.as_tensor(scale).cuda()).cpu().numpy()
+    ref = (M.compute_mfcc_batch(waves, utterance_length=L) - mean) / scale
+    assert got.shape == (5, 20 * L)
+    assert np.abs(got - ref).max() < 2e-2 / scale.min() + 1e-4
+
+
+def test_gemm_with_padded_leading_dimensions(cuda):
+    """lda / ldb / ldc larger than the logical widths (sub-matrices of bigger buffers), odd sizes."""
+    import lipasr._native as N
+
+    h = N.get_handle(0)
+    rng = np.random.default_rng(0)
+    M_, Nn, K = 45, 19, 77
+    A_full = rng.integers(-3, 4, (M_, K + 5)).astype(np.float32)
+    B_full = rng.integers(-3, 4, (K, Nn + 3)).astype(np.float32)
+    C_full = np.full((M_, Nn + 7), -1.0, np.float32)
+    At, Bt, Ct = dev(A_full), dev(B_full), dev(C_full)
+    N.check(N.lib.lipasr_gemm_f32(h.h, 0, 0, M_, Nn, K, N.ptr(At), K + 5, N.ptr(Bt), Nn + 3, N.ptr(Ct), Nn + 7, N.stream_ptr()))
+    out = Ct.cpu().numpy()
+    np.testing.assert_array_equal(out[:, :Nn], A_full[:, :K].astype(np.float64) @ B_full[:, :Nn].astype(np.float64))
+    assert np.all(out[:, Nn:] == -1.0)  # nothing written past the logical width
+
+
+def test_noise_models_on_odd_lengths(cuda):
+    from lipasr.attacks import add_noise, add_white_noise, add_white_noise_with_snr
+
+    x = (0.1 * np.random.default_rng(0).standard_normal(22051)).astype(np.float32)  # odd length
+    for fn, args in ((add_white_noise, (0.05,)), (add_noise, (0.1, 0.02)), (add_white_noise_with_snr, (10.0,))):
+        y = fn(x, *args)
+        y = y.cpu().numpy() if torch.is_tensor(y) else np.asarray(y)
+        assert y.shape == x.shape and np.isfinite(y).all() and not np.array_equal(y, x)
+    snr = add_white_noise_with_snr(x, 10.0)
+    snr = snr.cpu().numpy() if torch.is_tensor(snr) else np.asarray(snr)
+    got_db = 10 * np.log10(np.mean(x.astype(np.float64) ** 2) / np.mean((snr - x).astype(np.float64) ** 2))
+    assert abs(got_db - 10.0) < 0.3
