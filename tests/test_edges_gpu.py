@@ -144,3 +144,24 @@ def test_noise_models_on_odd_lengths(cuda):
     snr = snr.cpu().numpy() if torch.is_tensor(snr) else np.asarray(snr)
     got_db = 10 * np.log10(np.mean(x.astype(np.float64) ** 2) / np.mean((snr - x).astype(np.float64) ** 2))
     assert abs(got_db - 10.0) < 0.3
+
+
+def test_class_count_limit(cuda):
+    """The plan covers 1..32 classes (the class dimension is one MFMA tile in the loss epilogue and the Gram solver);
+    32 works end to end, 33 is refused at creation with a message that says so."""
+    spec = [P.LayerSpec(50, 48, True, 0.0, True), P.LayerSpec(48, 32, False, 0.0, True)]
+    p = P.init_params(spec, seed=3, dtype=np.float32, nonneg_init=True)
+    m = build_model(spec, max_batch=64)
+    load_params(m, p)
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((37, 50)).astype(np.float32)
+    y = P.to_categorical(rng.integers(0, 32, 37), 32)
+    m.train_fwd_bwd(dev(x), dev(y), dropout=False)
+    ref = P.forward_backward(spec, p.astype(np.float64), x.astype(np.float64), y.astype(np.float64), masks=None, training=True)
+    got = grads_of(m, spec)
+    for l in range(2):
+        assert rel_err(got["dW"][l], ref["dW"][l]) < 1e-4
+    assert abs(float(m._loss_rows[:37].mean()) - ref["loss"]) < 1e-4 * abs(ref["loss"])
+    np.testing.assert_array_equal(m._correct_rows[:37].cpu().numpy(), (ref["prob"].argmax(1) == y.argmax(1)).astype(np.float32))
+    with pytest.raises(ValueError, match="32"):
+        build_model([P.LayerSpec(50, 48, True, 0.0, True), P.LayerSpec(48, 33, False, 0.0, True)], max_batch=64)
