@@ -11,14 +11,13 @@ models on the device (Philox RNG) and the noisy-audio -> MFCC dataset helpers.
 """
 from __future__ import annotations
 
-import ctypes as C
 import math
 
 import numpy as np
 import torch
 
 from . import _native as N
-from .extract_features_construct_dataset import MfccExtractor, read_wav, _extractor
+from .extract_features_construct_dataset import read_wav, _extractor
 from .keras import Model, to_categorical
 
 

@@ -16,7 +16,6 @@ feature and label buffers are double-buffered and hipEvents carry the two depend
 from __future__ import annotations
 
 import ctypes as C
-import math
 
 import torch
 

@@ -19,7 +19,7 @@ import torch
 
 from . import _native as N
 from .Constraints import customConstraint, norm_constraint, norm_constraint_FISTA, simple_norm_constraint  # noqa: F401
-from .extract_features_construct_dataset import (  # noqa: F401
+from .extract_features_construct_dataset import (  # noqa: F401  (re-exported: the Speaker-recognition copy has the same read-outs)
     N_MFCC,
     MfccExtractor,
     extract_features,

@@ -1,7 +1,6 @@
 """CPU suite: the C-ABI library loads and exports every symbol include/lipasr.h declares, its host-side
 tables equal the oracle's, argument validation works without a GPU, and the host logic of the package
 (datasets, visit orders, shard bounds) behaves like the reference."""
-import ctypes as C
 import os
 import re
 

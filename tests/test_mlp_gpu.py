@@ -5,7 +5,6 @@ Tolerances: the HIP path is exact-fp32 fma chains (v_mfma_f32_32x32x2_f32) in a 
 order than the oracle; activations/gradients agree to ~1e-5 relative to the tensor's max, logits to
 well inside BASELINE's 1e-3 relative bound with identical argmax.
 """
-import ctypes as C
 import os
 
 import numpy as np

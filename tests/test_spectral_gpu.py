@@ -4,7 +4,6 @@ Tolerances: sigma and projected kernels agree to 2e-5 relative.  The HIP path su
 different association than LAPACK and takes sigma from a Gram eigenvalue (product) or a converged
 power iteration (per layer); the reference's own float32 SVD is good to ~1e-6.
 """
-import ctypes as C
 import os
 
 import numpy as np
