@@ -772,7 +772,7 @@ __global__ __launch_bounds__(256) void stft_mel_wave_kernel(StftArgs a, const fl
 struct DftArgs {
   const float* ypad;
   const float* table;  // [k_rows][n_tiles*64]
-  int hop, k_rows, n_tiles, rpc, n_frames, total_rows;
+  int hop, n_fft, k_rows, n_tiles, rpc, n_frames, total_rows;
   const int* mel_start;
   const int* mel_len;
   const int* mel_off;
@@ -797,13 +797,13 @@ __global__ __launch_bounds__(256) void reflect_pad_kernel(const float* __restric
   }
 }
 
-__global__ __launch_bounds__(64 * kDftMaxTiles) void dft_mel_kernel(DftArgs a) {
+__global__ __launch_bounds__(64 * kDftMaxTiles) __attribute__((amdgpu_waves_per_eu(4, 4))) void dft_mel_kernel(DftArgs a) {
   extern __shared__ __attribute__((aligned(16))) float dsm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x, n_waves = nthreads >> 6;
   const int row0 = blockIdx.x * kDftRows;
   {
     const float* src = a.ypad + (size_t)row0 * a.hop;
-    const int n_a = (kDftRows - 1) * a.hop + a.k_rows;
+    const int n_a = (kDftRows - 1) * a.hop + a.n_fft + 1;
     for (int i = tid; i < n_a; i += nthreads) dsm[i] = src[i];
   }
   __syncthreads();
@@ -813,8 +813,13 @@ __global__ __launch_bounds__(64 * kDftMaxTiles) void dft_mel_kernel(DftArgs a) {
 #pragma unroll
   for (int q = 0; q < 16; ++q) { re0[q] = 0.f; im0[q] = 0.f; re1[q] = 0.f; im1[q] = 0.f; }
   const float* bp = a.table + (size_t)kk * ld + wave * 64 + li;
-  const float* ap0 = dsm + li * a.hop + kk;
-  const float* ap1 = ap0 + 32 * a.hop;
+  // row n of the folded table meets x[n] + x[(N - n) mod N] (real part) and x[n] - x[(N - n) mod N] (imaginary part)
+  // (n = 2 s + kk walks forward from x[kk], its partner N - n backward from x[N - kk]; n = 0 meets x[N], one
+  // past the frame, under a zero weight (w[0] = 0); padded rows n > N/2 stay inside the frame and meet zero rows)
+  const float* fw0 = dsm + li * a.hop + kk;
+  const float* bw0 = dsm + li * a.hop + a.n_fft - kk;
+  const float* fw1 = fw0 + 32 * a.hop;
+  const float* bw1 = bw0 + 32 * a.hop;
   const int n_groups = a.k_rows / (2 * kDftGroup);
   float br0[kDftGroup], bi0[kDftGroup], br1[kDftGroup], bi1[kDftGroup];
 #define LP_DFT_LOAD(BR, BI, G)                                          \
@@ -825,12 +830,12 @@ __global__ __launch_bounds__(64 * kDftMaxTiles) void dft_mel_kernel(DftArgs a) {
   }
 #define LP_DFT_MAC(BR, BI, G)                                           \
   _Pragma("unroll") for (int u = 0; u < kDftGroup; ++u) {               \
-    const int k0_ = 2 * ((G) * kDftGroup + u);                          \
-    const float a0_ = ap0[k0_], a1_ = ap1[k0_];                         \
-    re0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0_, BR[u], re0, 0, 0, 0); \
-    im0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0_, BI[u], im0, 0, 0, 0); \
-    re1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_, BR[u], re1, 0, 0, 0); \
-    im1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_, BI[u], im1, 0, 0, 0); \
+    const int s_ = 2 * ((G) * kDftGroup + u);                           \
+    const float p0_ = fw0[s_], q0_ = bw0[-s_], p1_ = fw1[s_], q1_ = bw1[-s_]; \
+    re0 = __builtin_amdgcn_mfma_f32_32x32x2f32(p0_ + q0_, BR[u], re0, 0, 0, 0); \
+    im0 = __builtin_amdgcn_mfma_f32_32x32x2f32(p0_ - q0_, BI[u], im0, 0, 0, 0); \
+    re1 = __builtin_amdgcn_mfma_f32_32x32x2f32(p1_ + q1_, BR[u], re1, 0, 0, 0); \
+    im1 = __builtin_amdgcn_mfma_f32_32x32x2f32(p1_ - q1_, BI[u], im1, 0, 0, 0); \
   }
   LP_DFT_LOAD(br0, bi0, 0)
   for (int g = 0; g < n_groups; g += 2) {
@@ -1089,11 +1094,11 @@ static int launch_from_22k(const MfccPlan* p, const float* y, int batch, int L, 
                        p->d_ypad, stride);
     LP_LAUNCH_CHECK();
     DftArgs d;
-    d.ypad = p->d_ypad; d.table = p->d_dft; d.hop = p->hop; d.k_rows = p->dft_krows; d.n_tiles = p->dft_tiles;
+    d.ypad = p->d_ypad; d.table = p->d_dft; d.hop = p->hop; d.n_fft = p->n_fft; d.k_rows = p->dft_krows; d.n_tiles = p->dft_tiles;
     d.rpc = p->dft_rpc; d.n_frames = p->n_frames; d.total_rows = batch * p->dft_rpc;
     d.mel_start = p->d_mel_start; d.mel_len = p->d_mel_len; d.mel_off = p->d_mel_off; d.mel_w = p->d_mel_w;
     d.db = p->d_db; d.fmax = p->d_fmax;
-    const int n_a = (kDftRows - 1) * p->hop + p->dft_krows, n_p = kDftRows * (p->dft_tiles * 32 + 1);
+    const int n_a = (kDftRows - 1) * p->hop + p->n_fft + 1, n_p = kDftRows * (p->dft_tiles * 32 + 1);
     const size_t dl = (size_t)(n_a > n_p ? n_a : n_p) * sizeof(float);
     if (dl > 48 * 1024)
       LP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dft_mel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1191,9 +1196,9 @@ int lipasr_mfcc_plan_ex(lipasr_handle_t h, int sr_in, int n_samp, int batch_max,
   MelSparse ms = mel_sparse(n_fft);
   if (dft) {
     p->dft_tiles = (1 + n_fft / 2 + 31) / 32;
-    p->dft_krows = ((n_fft + 2 * kDftGroup - 1) / (2 * kDftGroup)) * (2 * kDftGroup);
+    p->dft_krows = ((n_fft / 2 + 1 + 2 * kDftGroup - 1) / (2 * kDftGroup)) * (2 * kDftGroup);  // folded: rows 0..N/2
     p->dft_rpc = (p->n_y + 2 * (n_fft / 2) + hop - 1) / hop;
-    const size_t npad = ((size_t)batch_max * p->dft_rpc + kDftRows + 1) * hop + p->dft_krows;
+    const size_t npad = ((size_t)batch_max * p->dft_rpc + kDftRows + 1) * hop + n_fft + 64;
     if ((rc = upload(&p->d_dft, dft_table(n_fft, p->dft_krows, p->dft_tiles))) != LIPASR_OK) { mfcc_plan_free(p); return rc; }
     if (hipMalloc(&p->d_ypad, npad * sizeof(float)) != hipSuccess || hipMemset(p->d_ypad, 0, npad * sizeof(float)) != hipSuccess) {
       mfcc_plan_free(p);

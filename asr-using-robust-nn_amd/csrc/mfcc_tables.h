@@ -231,23 +231,28 @@ inline MelPairs mel_pairs() {
   return mp;
 }
 
-// Windowed real-DFT matrix for an STFT evaluated as a contraction (n_fft <= 512, any parity):
-//   T[k][t*64 + j]      =  hann[k] cos(2 pi k b / n_fft)     b = 32 t + j,  j < 32
-//   T[k][t*64 + 32 + j] = -hann[k] sin(2 pi k b / n_fft)
-// rows k >= n_fft and bins b > n_fft/2 are zero; k_rows rows of n_tiles*64 floats.  Angles are reduced
-// exactly (k*b mod n_fft) before the fp64 evaluation.
+// Windowed real-DFT matrix for an STFT evaluated as a contraction (n_fft <= 510, any parity), folded on the
+// symmetry of a real input under a symmetric window (periodic Hann: w[N-n] = w[n]):
+//   Re X[b] =  sum_{n=0}^{N/2} c_n w[n] cos(2 pi n b / N) * (x[n] + x[(N-n) mod N])
+//   Im X[b] = -sum_{n=0}^{N/2} c_n w[n] sin(2 pi n b / N) * (x[n] - x[(N-n) mod N])
+// with c_n = 1/2 where n pairs with itself (n = 0, and n = N/2 for even N) and 1 elsewhere: half the rows of the
+// plain DFT matrix.  Layout: T[n][t*64 + j] = re weight, T[n][t*64 + 32 + j] = im weight, b = 32 t + j; rows
+// n > N/2 and bins b > N/2 are zero; k_rows rows of n_tiles*64 floats.  Angles are reduced exactly (n*b mod N)
+// before the fp64 evaluation.
 inline std::vector<float> dft_table(int n_fft, int k_rows, int n_tiles) {
   const int ld = n_tiles * 64, n_bins = 1 + n_fft / 2;
   std::vector<float> T((size_t)k_rows * ld, 0.0f);
   std::vector<double> w = hann_periodic_f64(n_fft);
-  for (int k = 0; k < n_fft; ++k)
+  for (int n = 0; n <= n_fft / 2; ++n) {
+    const double c = (n == 0 || 2 * n == n_fft) ? 0.5 : 1.0;
     for (int b = 0; b < n_bins; ++b) {
-      const long long r = ((long long)k * b) % n_fft;
+      const long long r = ((long long)n * b) % n_fft;
       const double ang = 2.0 * kPi * (double)r / (double)n_fft;
       const int t = b >> 5, j = b & 31;
-      T[(size_t)k * ld + t * 64 + j] = (float)(w[k] * std::cos(ang));
-      T[(size_t)k * ld + t * 64 + 32 + j] = (float)(-w[k] * std::sin(ang));
+      T[(size_t)n * ld + t * 64 + j] = (float)(c * w[n] * std::cos(ang));
+      T[(size_t)n * ld + t * 64 + 32 + j] = (float)(-c * w[n] * std::sin(ang));
     }
+  }
   return T;
 }
 
