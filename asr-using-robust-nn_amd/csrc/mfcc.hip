@@ -29,7 +29,6 @@ struct MfccPlan {
   bool dft = false;          // short-window variant: STFT as an MFMA contraction (dft_mel_kernel)
   int dft_krows = 0, dft_tiles = 0, dft_rpc = 0;
   float* d_dft = nullptr;    // [dft_krows][dft_tiles*64] windowed DFT matrix
-  float* d_ypad = nullptr;   // reflect-padded clips, dft_rpc*hop floats each (+ a zero tail)
   bool identity = false;  // sr_in == 22050
   float* d_h = nullptr;   // [up][taps]
   int* d_noff = nullptr;  // [up]
@@ -62,7 +61,7 @@ struct MfccPlan {
 
 void mfcc_plan_free(MfccPlan* p) {
   if (!p) return;
-  void* ptrs[] = {p->d_dft, p->d_ypad, p->d_twB, p->d_mel_wlo, p->d_mel_whi, p->d_mel_pstart, p->d_mel_plen, p->d_hband, p->d_lo, p->d_h, p->d_noff, p->d_hann, p->d_tw, p->d_mel_start, p->d_mel_len, p->d_mel_off,
+  void* ptrs[] = {p->d_dft, p->d_twB, p->d_mel_wlo, p->d_mel_whi, p->d_mel_pstart, p->d_mel_plen, p->d_hband, p->d_lo, p->d_h, p->d_noff, p->d_hann, p->d_tw, p->d_mel_start, p->d_mel_len, p->d_mel_off,
                   p->d_mel_w, p->d_dct, p->d_y, p->d_db, p->d_fmax};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
@@ -761,17 +760,19 @@ __global__ __launch_bounds__(256) void stft_mel_wave_kernel(StftArgs a, const fl
 // librosa.feature.mfcc(win_length=441, n_fft=441, hop_length=220), 1 + 22050/220 = 101 frames): the windowed
 // real DFT evaluated as an fp32 MFMA contraction  frames[rows][n_fft] x table[n_fft][re | im].
 //
-// Layout: every clip is reflect-padded into rpc*hop floats (rpc = rows per clip, so that global frame row r
-// starts at ypad + r*hop for ALL clips: the overlapping frames are just a matrix with leading dimension hop;
-// rows frame >= n_frames of a clip are computed and dropped).  One workgroup takes 64 consecutive rows: their
+// Layout: every clip is thought of as reflect-padded into rpc*hop floats (rpc = rows per clip), so that global
+// frame row r starts at position r*hop for ALL clips: the overlapping frames are just a matrix with leading
+// dimension hop; rows frame >= n_frames of a clip are computed and dropped.  The padded layout is virtual -- the
+// reflection is applied while a workgroup stages its rows.  One workgroup takes 64 consecutive rows: their
 // samples (63*hop + K floats) are staged in LDS once, wavefront t owns the 32 bins of tile t and streams the
 // table's 64 columns (re, im) for those bins from L2 in double-buffered groups of 8 K-steps, four
 // 32x32x2 MFMA accumulators (2 row blocks x re/im).  Power goes back to LDS, then mel (CSR bank, sequential
 // fp32 like the FFT path), dB and the per-frame maximum, one wavefront per row.
 // ---------------------------------------------------------------------------------------------
 struct DftArgs {
-  const float* ypad;
+  const float* y;      // [batch][n_y] (unpadded: the reflect padding is applied while the rows are staged)
   const float* table;  // [k_rows][n_tiles*64]
+  int n_y, batch;
   int hop, n_fft, k_rows, n_tiles, rpc, n_frames, total_rows;
   const int* mel_start;
   const int* mel_len;
@@ -782,29 +783,29 @@ struct DftArgs {
 };
 constexpr int kDftRows = 64, kDftGroup = 8, kDftMaxTiles = 8;
 
-__global__ __launch_bounds__(256) void reflect_pad_kernel(const float* __restrict__ y, int n_y, int pad,
-                                                           float* __restrict__ ypad, int stride) {
-  const int u = blockIdx.y;
-  for (int j = blockIdx.x * 256 + threadIdx.x; j < stride; j += gridDim.x * 256) {
-    float v = 0.0f;
-    if (j < n_y + 2 * pad) {
-      int i = j - pad;  // np.pad(mode='reflect'): the edge sample is not repeated
-      if (i < 0) i = -i;
-      else if (i >= n_y) i = 2 * (n_y - 1) - i;
-      v = y[(size_t)u * n_y + i];
-    }
-    ypad[(size_t)u * stride + j] = v;
-  }
-}
-
 __global__ __launch_bounds__(64 * kDftMaxTiles) __attribute__((amdgpu_waves_per_eu(4, 4))) void dft_mel_kernel(DftArgs a) {
   extern __shared__ __attribute__((aligned(16))) float dsm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x, n_waves = nthreads >> 6;
   const int row0 = blockIdx.x * kDftRows;
   {
-    const float* src = a.ypad + (size_t)row0 * a.hop;
+    // position g of the virtual padded layout (clip c at c * rpc * hop, np.pad(y, N/2, 'reflect') inside): 64 rows
+    // span at most two clips because rpc > 64 is not required -- the clip index is found per element
     const int n_a = (kDftRows - 1) * a.hop + a.n_fft + 1;
-    for (int i = tid; i < n_a; i += nthreads) dsm[i] = src[i];
+    const int stride = a.rpc * a.hop, pad = a.n_fft / 2;
+    const long g0 = (long)row0 * a.hop;
+    for (int i = tid; i < n_a; i += nthreads) {
+      const long g = g0 + i;
+      const int c = (int)(g / stride);
+      const int j = (int)(g - (long)c * stride);
+      float v = 0.0f;
+      if (c < a.batch && j < a.n_y + 2 * pad) {
+        int k = j - pad;  // the edge sample is not repeated
+        if (k < 0) k = -k;
+        else if (k >= a.n_y) k = 2 * (a.n_y - 1) - k;
+        v = a.y[(size_t)c * a.n_y + k];
+      }
+      dsm[i] = v;
+    }
   }
   __syncthreads();
   const int li = lane & 31, kk = lane >> 5;
@@ -1089,12 +1090,8 @@ static int launch_from_22k(const MfccPlan* p, const float* y, int batch, int L, 
   a.db = p->d_db; a.fmax = p->d_fmax;
   a.stage_mask = p->stage_mask;
   if (p->dft) {
-    const int stride = p->dft_rpc * p->hop;
-    hipLaunchKernelGGL(reflect_pad_kernel, dim3((stride + 1023) / 1024, batch), dim3(256), 0, st, y, p->n_y, p->n_fft / 2,
-                       p->d_ypad, stride);
-    LP_LAUNCH_CHECK();
     DftArgs d;
-    d.ypad = p->d_ypad; d.table = p->d_dft; d.hop = p->hop; d.n_fft = p->n_fft; d.k_rows = p->dft_krows; d.n_tiles = p->dft_tiles;
+    d.y = y; d.n_y = p->n_y; d.batch = batch; d.table = p->d_dft; d.hop = p->hop; d.n_fft = p->n_fft; d.k_rows = p->dft_krows; d.n_tiles = p->dft_tiles;
     d.rpc = p->dft_rpc; d.n_frames = p->n_frames; d.total_rows = batch * p->dft_rpc;
     d.mel_start = p->d_mel_start; d.mel_len = p->d_mel_len; d.mel_off = p->d_mel_off; d.mel_w = p->d_mel_w;
     d.db = p->d_db; d.fmax = p->d_fmax;
@@ -1198,13 +1195,7 @@ int lipasr_mfcc_plan_ex(lipasr_handle_t h, int sr_in, int n_samp, int batch_max,
     p->dft_tiles = (1 + n_fft / 2 + 31) / 32;
     p->dft_krows = ((n_fft / 2 + 1 + 2 * kDftGroup - 1) / (2 * kDftGroup)) * (2 * kDftGroup);  // folded: rows 0..N/2
     p->dft_rpc = (p->n_y + 2 * (n_fft / 2) + hop - 1) / hop;
-    const size_t npad = ((size_t)batch_max * p->dft_rpc + kDftRows + 1) * hop + n_fft + 64;
     if ((rc = upload(&p->d_dft, dft_table(n_fft, p->dft_krows, p->dft_tiles))) != LIPASR_OK) { mfcc_plan_free(p); return rc; }
-    if (hipMalloc(&p->d_ypad, npad * sizeof(float)) != hipSuccess || hipMemset(p->d_ypad, 0, npad * sizeof(float)) != hipSuccess) {
-      mfcc_plan_free(p);
-      set_error("lipasr_mfcc_plan_ex: padded-clip allocation failed");
-      return LIPASR_ENOMEM;
-    }
   }
   MelPairs mp = dft ? MelPairs() : mel_pairs();
   if (dft) { mp.wlo.assign(1, 0.f); mp.whi.assign(1, 0.f); mp.start.assign(1, 0); mp.len.assign(1, 0); }
