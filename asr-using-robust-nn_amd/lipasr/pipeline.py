@@ -26,14 +26,17 @@ from .parallel import DataParallel
 
 class TrainPipeline:
     def __init__(self, model, batch, sr_in=16000, n_samp=16000, utterance_length=44, rho=0.1, constraint="product",
-                 affine=None, pgd=None, dp=None, use_graph=True, per_layer_iters=4):
+                 affine=None, pgd=None, dp=None, use_graph=True, per_layer_iters=4, extractor=None):
         """constraint: 'product' (simple_norm_constraint, all layers), 'per_layer' (norm_constraint) or None.
         affine: (mean, scale) float64 device tensors [20*utterance_length] or None.
-        pgd: dict(eps=, eps_step=, max_iter=) for adversarial training on the standardised features."""
+        pgd: dict(eps=, eps_step=, max_iter=) for adversarial training on the standardised features.
+        extractor: a feature extractor ``f(waves, mean, scale, out=)`` replacing the 2048/512 MFCC plan, e.g.
+        ``speaker_recognition.WindowMfcc`` (441/220 windows -> 2020 features; pass utterance_length=101)."""
         self.model, self.batch, self.L = model, int(batch), int(utterance_length)
         self.dev = model._device
         self.h = N.get_handle(self.dev.index)
-        self.ex = MfccExtractor(sr_in, n_samp, self.batch, self.dev)
+        self.ex = MfccExtractor(sr_in, n_samp, self.batch, self.dev) if extractor is None else extractor
+        self._custom_ex = extractor is not None
         self.rho, self.constraint, self.pgd = float(rho), constraint, pgd
         self.dp = dp if dp is not None else DataParallel()
         self.use_graph = use_graph
@@ -116,7 +119,10 @@ class TrainPipeline:
             if features is not None:
                 self._feats2[b][:bsz].copy_(features)
             else:
-                self.ex(waves, self.L, self.mean, self.scale, out=self._feats2[b][:bsz])
+                if self._custom_ex:
+                    self.ex(waves, self.mean, self.scale, out=self._feats2[b][:bsz])
+                else:
+                    self.ex(waves, self.L, self.mean, self.scale, out=self._feats2[b][:bsz])
             self._labels2[b][:bsz].copy_(y_onehot)
             self._ev_feat[b].record(self.mfcc_stream)
         with torch.cuda.stream(self.stream):

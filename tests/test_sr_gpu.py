@@ -156,3 +156,38 @@ def test_sr_model_step_and_constraint(cuda, which):
     for l in range(6):
         assert rel_err(after.W[l], want[l]) < 2e-5, l
     assert abs(R.sigma_max(R.product_chain(after.W)) - norms[-1]) < 1e-4 * max(1.0, norms[-1])
+
+
+def test_sr_pipeline_step_matches_oracle(cuda):
+    """The end-to-end step with the 441/220 extractor plugged into TrainPipeline: windows -> MFCC (2020) -> fwd/bwd ->
+    Adam + NonNeg -> simple_norm_constraint(rho = 1), one batch of 64, dropout off, against the oracle."""
+    from lipasr.pipeline import TrainPipeline
+    from lipasr.speaker_recognition import WindowMfcc
+
+    spec = [P.LayerSpec(s.n_in, s.n_out, s.bn, 0.0, s.nonneg) for s in P.sr_constrained_spec()]
+    p = _state(spec, 11)
+    m = build_model(spec, max_batch=64)
+    load_params(m, p)
+    w = np.concatenate([_windows(), _windows(seed=4) * 0.5])[:8]
+    w = np.tile(w, (8, 1)).astype(np.float32)  # 64 windows
+    w += (0.01 * np.random.default_rng(0).standard_normal(w.shape)).astype(np.float32)
+    y = P.to_categorical(np.arange(64) % 20, 20)
+    raw = M.sr_mfcc_windows(w)
+    mean, scale = P.standard_scaler_fit(raw)  # standardised features, as the reference trains on (train_constraints.py:28-35)
+    affine = (torch.as_tensor(mean).cuda(), torch.as_tensor(scale).cuda())
+    pipe = TrainPipeline(m, batch=64, utterance_length=101, rho=1.0, constraint="product", extractor=WindowMfcc(batch_max=64), use_graph=True,
+                         affine=affine)
+    pipe.step(dev(w), dev(y))
+    pipe.synchronize()
+    feats = pipe.feats.cpu().numpy().astype(np.float64)
+    assert np.abs(feats - (raw - mean) / scale).max() < ATOL / scale.min() + 1e-4
+    p64, st = p.astype(np.float64), P.AdamState()
+    P.train_step(spec, p64, st, feats, y.astype(np.float64))   # from the GPU's features: isolates the classifier step
+    want, norms = R.simple_norm_constraint_pass([wk.astype(np.float32) for wk in p64.W], 1.0, [])
+    after = read_params(m, spec)
+    np.testing.assert_allclose(pipe.norms.cpu().numpy(), norms, rtol=2e-3)
+    for l in range(6):
+        # Adam's first step moves every weight by ~lr whatever the gradient's size: a sign flip of a ~1e-7 gradient
+        # is a 2e-3 move, so the bulk is compared tightly and the tail loosely (as test_pipeline_gpu.py does)
+        d = np.abs(after.W[l] - want[l]) / np.abs(want[l]).max()
+        assert np.quantile(d, 0.999) < 2e-3 and d.max() < 5e-2, (l, np.quantile(d, 0.999), d.max())
