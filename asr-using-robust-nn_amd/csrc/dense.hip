@@ -18,6 +18,7 @@
 namespace lipasr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 enum Epi {
   EPI_STORE = 0,
@@ -81,7 +82,18 @@ struct GemmArgs {
   float* dz;               // [M][N] (p - y) * inv_batch
   float* loss_rows;        // [M]
   float* correct_rows;     // [M]
+  // 0: exact fp32 (v_mfma_f32_32x32x2_f32).  1: operands rounded to bf16 (RNE) at the MFMA, fp32 accumulate
+  // (v_mfma_f32_32x32x16_bf16): BASELINE config 2's arithmetic; memory stays fp32.
+  int bf16;
 };
+
+// eight consecutive-k fp32 operand values of a lane -> one bf16 fragment (lane (r, h) holds k = 8 h + j, j < 8)
+__device__ __forceinline__ bf16x8 to_bf16x8(const float (&v)[8]) {
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (__bf16)v[j];
+  return o;
+}
 
 // AMODE/BMODE 0: K contiguous in memory (operand(i,k) = P[i*ld + k]); 1: K strided (P[k*ld + i]).
 template <int MODE>
@@ -159,7 +171,7 @@ __device__ __forceinline__ float epilogue_elem(const GemmArgs& g, int step, int 
 
 // One workgroup = one 32x32 output tile; its NW wavefronts (4, or 16 for small outputs with a long K) split K
 // in 16-deep chunks, round-robin.  Operand fragments go global/L2 -> VGPR directly, one chunk ahead of the MFMAs.
-template <int AMODE, int BMODE, int NW>
+template <int AMODE, int BMODE, int NW, bool BF>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const int by, const int n_row_tiles) {
   constexpr int TS = 32;
   constexpr int TPR = 8;                       // threads per output row (one float4 each)
@@ -195,8 +207,13 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
       load_frag<AMODE>(g.A, g.lda, ai, cn * 16 + 8 * h, g.K, vecA, a1, aones);
       load_frag<BMODE>(g.B, g.ldb, bj, cn * 16 + 8 * h, g.K, vecB, b1);
     }
+    if (BF) {
+      // the chunk's 16 k values are exactly one 32x32x16 bf16 fragment per operand (same lane map as the loads)
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(to_bf16x8(a0), to_bf16x8(b0), acc, 0, 0, 0);
+    } else {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q], b0[q], acc, 0, 0, 0);
+      for (int q = 0; q < 8; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q], b0[q], acc, 0, 0, 0);
+    }
 #pragma unroll
     for (int q = 0; q < 8; ++q) { a0[q] = a1[q]; b0[q] = b1[q]; }
     c = cn;
@@ -330,9 +347,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
   }
 }
 
-template <int AMODE, int BMODE, int NW>
-__global__ __launch_bounds__(64 * NW) void gemm_f32_kernel(GemmArgs g) {
-  gemm_tile<AMODE, BMODE, NW>(g, blockIdx.x, blockIdx.y, gridDim.y);
+template <int AMODE, int BMODE, int NW, bool BF = false>  // BF: operands rounded to bf16 at the MFMA (compile-time: a
+__global__ __launch_bounds__(64 * NW) void gemm_f32_kernel(GemmArgs g) {  // run-time switch cost the fp32 path 6 %)
+  gemm_tile<AMODE, BMODE, NW, BF>(g, blockIdx.x, blockIdx.y, gridDim.y);
 }
 
 // Several independent GEMMs of one (AMODE, BMODE) in ONE launch: the six weight-gradient GEMMs of a training step
@@ -345,14 +362,14 @@ struct GemmGroup {
   GemmArgs g[kMaxGroup];
 };
 
-template <int AMODE, int BMODE, int NW>
+template <int AMODE, int BMODE, int NW, bool BF = false>
 __global__ __launch_bounds__(64 * NW) void gemm_f32_grouped_kernel(GemmGroup grp) {
   int p = 0;
   while (p + 1 < grp.n && (int)blockIdx.x >= grp.tile_start[p + 1]) ++p;
   const GemmArgs& g = grp.g[p];
   const int local = blockIdx.x - grp.tile_start[p];
   const int ntx = (g.N + 31) / 32;
-  gemm_tile<AMODE, BMODE, NW>(g, local % ntx, local / ntx, (g.M + 31) / 32);
+  gemm_tile<AMODE, BMODE, NW, BF>(g, local % ntx, local / ntx, (g.M + 31) / 32);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -416,7 +433,7 @@ __device__ __forceinline__ void tile_store(float* __restrict__ S, int tid, const
   }
 }
 
-template <int AMODE, int BMODE>
+template <int AMODE, int BMODE, bool BF = false>
 __global__ __launch_bounds__(512) void gemm_lds_kernel(GemmArgs g) {
   constexpr int TS = 64;
   __shared__ __attribute__((aligned(16))) float lds[2 * 2 * kLdsBK * kLdsLD];  // [buf][A|B][32][68]; reused as [2][64][64]
@@ -437,8 +454,11 @@ __global__ __launch_bounds__(512) void gemm_lds_kernel(GemmArgs g) {
   tile_store<BMODE>(lds + kLdsBK * kLdsLD, tid, rb);
   __syncthreads();
   for (int t = 0; t < nst; ++t) {
-    const float* As = lds + (t & 1) * 2 * kLdsBK * kLdsLD + (16 * kh + h) * kLdsLD + 32 * wi + r;
-    const float* Bs = lds + (t & 1) * 2 * kLdsBK * kLdsLD + kLdsBK * kLdsLD + (16 * kh + h) * kLdsLD + 32 * wj + r;
+    // fp32: lane half h takes k = h + 2 s of its 16 (one 32x32x2 per s); bf16: k = 8 h + s (one 32x32x16 for all)
+    constexpr int kstr = BF ? kLdsLD : 2 * kLdsLD;
+    const int koff = BF ? 8 * h : h;
+    const float* As = lds + (t & 1) * 2 * kLdsBK * kLdsLD + (16 * kh + koff) * kLdsLD + 32 * wi + r;
+    const float* Bs = lds + (t & 1) * 2 * kLdsBK * kLdsLD + kLdsBK * kLdsLD + (16 * kh + koff) * kLdsLD + 32 * wj + r;
     if (t + 1 < nst) {
       ra = tile_fetch<AMODE>(g.A, g.lda, m0, m_real, (t + 1) * kLdsBK, g.K, ones, g.M - 1, tid);
       rb = tile_fetch<BMODE>(g.B, g.ldb, n0, g.N, (t + 1) * kLdsBK, g.K, false, 0, tid);
@@ -446,11 +466,15 @@ __global__ __launch_bounds__(512) void gemm_lds_kernel(GemmArgs g) {
     float av[8], bv[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-      av[s] = As[2 * s * kLdsLD];
-      bv[s] = Bs[2 * s * kLdsLD];
+      av[s] = As[s * kstr];
+      bv[s] = Bs[s * kstr];
     }
+    if (BF) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(to_bf16x8(av), to_bf16x8(bv), acc, 0, 0, 0);
+    } else {
 #pragma unroll
-    for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc, 0, 0, 0);
+      for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc, 0, 0, 0);
+    }
     if (t + 1 < nst) {
       float* An = lds + ((t + 1) & 1) * 2 * kLdsBK * kLdsLD;
       tile_store<AMODE>(An, tid, ra);
@@ -542,7 +566,8 @@ static int launch_gemm_group_tn(const GemmArgs* gs, int n, hipStream_t st) {
     grp.n = k;
     grp.tile_start[k] = tiles;
     const size_t lds = (size_t)(4 * 32 * 32 + 4 * 8 * 8) * sizeof(float);
-    hipLaunchKernelGGL((gemm_f32_grouped_kernel<1, 1, 4>), dim3(tiles), dim3(256), lds, st, grp);
+    if (gs[done].bf16) hipLaunchKernelGGL((gemm_f32_grouped_kernel<1, 1, 4, true>), dim3(tiles), dim3(256), lds, st, grp);
+    else hipLaunchKernelGGL((gemm_f32_grouped_kernel<1, 1, 4, false>), dim3(tiles), dim3(256), lds, st, grp);
     LP_LAUNCH_CHECK();
     done += k;
   }
@@ -559,17 +584,23 @@ static bool use_lds_gemm(int M, int N, int K) {
   return legal && tiles >= 224;  // measured on MI355X (scratch/time_gemm.py): it wins only when >= ~one tile per CU
 }
 
-template <int AMODE, int BMODE, int NW>
-static void launch_gemm_t(const GemmArgs& g, hipStream_t st) {
+template <int AMODE, int BMODE, int NW, bool BF>
+static void launch_gemm_tb(const GemmArgs& g, hipStream_t st) {
   const dim3 grid((g.N + 31) / 32, (g.M + 31) / 32);
   const size_t lds = (size_t)(NW * 32 * 32 + 4 * 8 * 8) * sizeof(float);
   static bool attr_set = false;
   if (lds > 48 * 1024 && !attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<AMODE, BMODE, NW>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<AMODE, BMODE, NW, BF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_f32_kernel<AMODE, BMODE, NW>), grid, dim3(64 * NW), lds, st, g);
+  hipLaunchKernelGGL((gemm_f32_kernel<AMODE, BMODE, NW, BF>), grid, dim3(64 * NW), lds, st, g);
+}
+
+template <int AMODE, int BMODE, int NW>
+static void launch_gemm_t(const GemmArgs& g, hipStream_t st) {
+  if (g.bf16) launch_gemm_tb<AMODE, BMODE, NW, true>(g, st);
+  else launch_gemm_tb<AMODE, BMODE, NW, false>(g, st);
 }
 
 static int launch_gemm(int amode, int bmode, const GemmArgs& g, hipStream_t st) {
@@ -588,10 +619,14 @@ static int launch_gemm(int amode, int bmode, const GemmArgs& g, hipStream_t st) 
   }
   if (use_lds_gemm(g.M, g.N, g.K)) {
     const dim3 grid((g.N + 63) / 64, (g.M + 63) / 64);
-    if (amode == 0 && bmode == 0) hipLaunchKernelGGL((gemm_lds_kernel<0, 0>), grid, dim3(512), 0, st, g);
-    else if (amode == 0 && bmode == 1) hipLaunchKernelGGL((gemm_lds_kernel<0, 1>), grid, dim3(512), 0, st, g);
-    else if (amode == 1 && bmode == 0) hipLaunchKernelGGL((gemm_lds_kernel<1, 0>), grid, dim3(512), 0, st, g);
-    else hipLaunchKernelGGL((gemm_lds_kernel<1, 1>), grid, dim3(512), 0, st, g);
+#define LP_LDS(A_, B_)                                                                              \
+  {                                                                                                 \
+    if (g.bf16) hipLaunchKernelGGL((gemm_lds_kernel<A_, B_, true>), grid, dim3(512), 0, st, g);     \
+    else hipLaunchKernelGGL((gemm_lds_kernel<A_, B_, false>), grid, dim3(512), 0, st, g);           \
+  }
+    if (amode == 0 && bmode == 0) LP_LDS(0, 0) else if (amode == 0 && bmode == 1) LP_LDS(0, 1)
+    else if (amode == 1 && bmode == 0) LP_LDS(1, 0) else LP_LDS(1, 1)
+#undef LP_LDS
     LP_LAUNCH_CHECK();
     return LIPASR_OK;
   }
@@ -1071,6 +1106,7 @@ static int forward_infer(lipasr_mlp* m, const float* params, const float* bnstat
       // when H aliases A (no BN, no dropout) the ReLU output lands in H == A directly
       g.aux = (keep_a && L.offH != L.offA) ? (m->ws + L.offA) : nullptr;
     }
+    g.bf16 = m->compute_bf16;
     int rc = launch_gemm(0, 1, g, st);
     if (rc != LIPASR_OK) return rc;
     hin = outp;
@@ -1097,6 +1133,7 @@ static int backward_infer(lipasr_mlp* m, const float* params, const float* bnsta
         g.mvar = bnstate + P.offmv;
       }
       g.aux = m->ws + P.offA;
+      g.bf16 = m->compute_bf16;
       int rc = launch_gemm(0, 0, g, st);
       if (rc != LIPASR_OK) return rc;
       gin = pp[cur];
@@ -1108,6 +1145,7 @@ static int backward_infer(lipasr_mlp* m, const float* params, const float* bnsta
       g.x0 = x0;
       g.alpha = alpha;
       g.eps = eps;
+      g.bf16 = m->compute_bf16;
       int rc = launch_gemm(0, 0, g, st);
       if (rc != LIPASR_OK) return rc;
     }
@@ -1154,6 +1192,7 @@ int lipasr_mlp_train_fwd_bwd(lipasr_mlp_t m, const float* params, float* bnstate
       g.loss_rows = loss_rows;
       g.correct_rows = correct_rows;
     }
+    g.bf16 = m->compute_bf16;
     rc = launch_gemm(0, 1, g, st);
     if (rc != LIPASR_OK) return rc;
     if (!last && L.offH != L.offA) {
@@ -1200,6 +1239,7 @@ int lipasr_mlp_train_fwd_bwd(lipasr_mlp_t m, const float* params, float* bnstate
     gx.drop = drop_for_layer(m, l - 1, dropout);
     gx.part = part;
     if (P.bn) gx.save_mean = ws + P.offMean;
+    gx.bf16 = m->compute_bf16;
     rc = launch_gemm(0, 0, gx, st);
     if (rc != LIPASR_OK) return rc;
     if (P.bn) {
@@ -1224,6 +1264,7 @@ int lipasr_mlp_train_fwd_bwd(lipasr_mlp_t m, const float* params, float* bnstate
     gw[l] = gemm_args(lin, L.n_in, gin, L.n_out, grads + L.offW, L.n_out, L.n_in + 1, L.n_out, batch, EPI_STORE);
     gw[l].ones_row = 1;
     gw[l].extra_out = grads + L.offb;
+    gw[l].bf16 = m->compute_bf16;
   }
   return launch_gemm_group_tn(gw, Lc, st);
 }
@@ -1313,6 +1354,13 @@ int lipasr_mlp_output_vjp(lipasr_mlp_t m, const float* params, const float* bnst
                      probs_out, m->ws + m->offDzLast);
   LP_LAUNCH_CHECK();
   return backward_infer(m, params, bnstate, batch, dx, nullptr, nullptr, 0.0f, 0.0f, st);
+}
+
+int lipasr_mlp_set_compute(lipasr_mlp_t m, int mode) {
+  LP_CHECK_ARG(m != nullptr, "lipasr_mlp_set_compute: null plan");
+  LP_CHECK_ARG(mode == 0 || mode == 1, "lipasr_mlp_set_compute: mode %d (0 = fp32, 1 = bf16 operands)", mode);
+  m->compute_bf16 = mode;
+  return LIPASR_OK;
 }
 
 }  // extern "C"

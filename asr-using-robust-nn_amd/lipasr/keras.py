@@ -317,7 +317,12 @@ class TensorBoard(Callback):
 
 # ------------------------------------------------------------------------------------------------
 class Model:
-    def __init__(self, inputs, outputs, device=None, seed=0, max_batch=1024):
+    def __init__(self, inputs, outputs, device=None, seed=0, max_batch=1024, compute_dtype="float32"):
+        """compute_dtype: "float32" (exact fp32 MFMA: the parity arithmetic) or "bfloat16" (GEMM operands rounded to
+        bf16 at the matrix instruction, fp32 accumulation -- BASELINE config 2; everything else stays fp32)."""
+        if compute_dtype not in ("float32", "bfloat16"):
+            raise ValueError("compute_dtype must be 'float32' or 'bfloat16'")
+        self._compute_dtype = compute_dtype
         chain = []
         node = outputs
         while node is not None:
@@ -378,6 +383,8 @@ class Model:
         N.check(N.lib.lipasr_mlp_create(self._h.h, nb, N.int_array(self._widths), N.int_array(bn), N.float_array(drop),
                                         N.int_array(nonneg), self._max_batch, C.byref(plan)))
         self._plan = plan
+        if self._compute_dtype == "bfloat16":
+            N.check(N.lib.lipasr_mlp_set_compute(plan, 1))
         n_params, n_state = N.sz(), N.sz()
         N.check(N.lib.lipasr_mlp_sizes(plan, C.byref(n_params), C.byref(n_state)))
         dev = self._device

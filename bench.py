@@ -109,7 +109,8 @@ def run_config(args, batch, rank, world, device, steps, warmup, profile):
 
     n_batches = 8
     waves, y = make_pool(n_batches * batch, device, seed=1234 + rank)
-    model = get_model(max_batch=batch, seed=0)  # same seed on every rank: replicas start identical
+    # same seed on every rank: replicas start identical
+    model = get_model(max_batch=batch, seed=0, compute_dtype="bfloat16" if args.bf16 else "float32")
     model.compile(optimizer="adam", loss=CategoricalCrossentropy(), metrics=["accuracy"])
     # A2 "affine, precomputed": StandardScaler fitted once on MFCCs of the pool
     ex = MfccExtractor(16000, 16000, batch, device)
@@ -180,6 +181,8 @@ def main():
     ap.add_argument("--pgd", type=int, default=0, help="PGD iterations per batch (config 5 uses 20)")
     ap.add_argument("--pgd-eps", type=float, default=0.5)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--bf16", action="store_true", help="classifier GEMM operands rounded to bf16 at the MFMA, fp32 accumulate (BASELINE config 2's "
+                    "arithmetic); the default and the headline are exact fp32")
     ap.add_argument("--pre-extracted", action="store_true", help="BASELINE config 2: train from resident (N,880) features, no MFCC stage")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--skip-b512", action="store_true")
@@ -238,7 +241,7 @@ def main():
                     "note": "whole step incl. BatchNorm, Adam and projection kernels; GEMM-only time is in profiles/"}
     out = {"metric": "utterances/sec (train, 1 s@16 kHz)", "value": round(value, 1), "unit": "utterances/sec", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
-           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.bf16 else "f32", "data": "synthetic",
            "config": {"workload": ("pre-extracted standardised (N,880) MFCC features" if args.pre_extracted else "raw 16 kHz waveform -> on-GPU MFCC")
                                   + " -> Lipschitz-constrained MLP train step (Adam+NonNeg, simple_norm_constraint rho=0.1)" + (f" + PGD-{args.pgd} adversarial inner loop" if args.pgd else "")
                                   + (", data-parallel RCCL gradient all-reduce" if world > 1 else ", 1xMI355X"),

@@ -217,6 +217,14 @@ int lipasr_mlp_project_per_layer(lipasr_mlp_t m, float* params, float rho, float
                                  int iters, float* sigmas_out, lipasr_stream_t stream);
 int lipasr_mlp_product_norm(lipasr_mlp_t m, const float* params, float* sigma_out, lipasr_stream_t stream);
 
+/* Arithmetic of the plan's GEMMs (forward, dX, dW; training and inference).  mode 0 (default): exact
+ * fp32 on v_mfma_f32_32x32x2_f32 -- the parity path (logits within 1e-3 of the reference-precision
+ * oracle).  mode 1: operands rounded to bf16 (round-to-nearest-even) at the matrix instruction,
+ * fp32 accumulation, on v_mfma_f32_32x32x16_bf16 -- BASELINE config 2's "bf16"; parameters,
+ * activations, statistics, the loss, Adam and the projections stay fp32.  Takes effect from the
+ * next launch; re-capture HIP graphs after changing it. */
+int lipasr_mlp_set_compute(lipasr_mlp_t m, int mode);
+
 /* model.predict (train_constraints.py:109, attacks.py:344): inference mode (BN moving statistics,
  * no dropout).  probs and/or logits [batch][classes], either may be NULL. */
 int lipasr_mlp_predict(lipasr_mlp_t m, const float* params, const float* bnstate, const float* x,

@@ -254,3 +254,60 @@ def test_weight_io_and_tensorboard_callback(cuda, tmp_path):
     m.fit(K.Dataset.from_tensor_slices((x, y)).batch(10), epochs=3, verbose=0, callbacks=[tb])
     lines = [json.loads(l) for l in open(tmp_path / "logs" / "scalars.jsonl")]
     assert [l["epoch"] for l in lines] == [0, 1, 2] and all("loss" in l for l in lines)
+
+
+def test_bf16_operand_mode(cuda):
+    """lipasr_mlp_set_compute(1) / Model(compute_dtype="bfloat16"): BASELINE config 2's arithmetic -- GEMM operands
+    rounded to bf16 at the MFMA, fp32 accumulation.  Not the parity path: the results must sit within bf16's 2^-8
+    operand rounding of the fp32 ones (and far outside fp32 noise, or the mode did nothing), the fp32 path must be
+    untouched, and a model must still train."""
+    from lipasr import keras as K
+
+    spec = P.vd_constrained_spec()
+    p = _random_state(spec, 5)
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((200, 880)).astype(np.float32)
+    y = P.to_categorical(rng.integers(0, 10, 200), 10)
+    ref = P.forward_infer(spec, p.astype(np.float64), x.astype(np.float64), return_logits=True)
+    out = {}
+    for dt in ("float32", "bfloat16"):
+        K.reset_layer_names()
+        m = build_model(spec, max_batch=256)
+        if dt == "bfloat16":
+            from lipasr import _native as N
+            N.check(N.lib.lipasr_mlp_set_compute(m._plan, 1))
+        load_params(m, p)
+        lg = m.predict_device(dev(x), logits=True).cpu().numpy()
+        m.train_fwd_bwd(dev(x), dev(y), dropout=False)
+        out[dt] = (lg, grads_of(m, spec))
+    rel32 = np.abs(out["float32"][0] - ref).max() / np.abs(ref).max()
+    rel16 = np.abs(out["bfloat16"][0] - ref).max() / np.abs(ref).max()
+    assert rel32 < 1e-4 and 1e-4 < rel16 < 3e-2, (rel32, rel16)
+    assert np.mean(out["bfloat16"][0].argmax(1) == ref.argmax(1)) > 0.97
+    # gradients: every backward GEMM rounds its operands and the BatchNorm backward subtracts batch means, so the
+    # relative error grows from the last layer (bf16 level) towards the first; the direction is what training needs
+    errs, coss = [], []
+    for l in range(6):
+        g32, g16 = out["float32"][1]["dW"][l], out["bfloat16"][1]["dW"][l]
+        errs.append(rel_err(g16, g32))
+        coss.append(float((g16 * g32).sum() / np.sqrt((g16 * g16).sum() * (g32 * g32).sum())))
+    assert 1e-5 < errs[5] < 2e-2, errs
+    assert min(coss) > 0.9, (errs, coss)
+    # a small model trains to the same place in either arithmetic
+    accs = {}
+    xs = rng.standard_normal((512, 32)).astype(np.float32)
+    w_true = rng.standard_normal((32, 4))
+    ys = P.to_categorical((xs @ w_true).argmax(1), 4)
+    for dt in ("float32", "bfloat16"):
+        K.reset_layer_names()
+        inp = K.Input((32,))
+        h = K.Dense(64, activation="relu")(inp)
+        h = K.BatchNormalization()(h)
+        o = K.Dense(4, activation="softmax")(h)
+        mm = K.Model(inputs=inp, outputs=o, max_batch=128, seed=3, compute_dtype=dt)
+        mm.compile(optimizer="adam", loss=K.CategoricalCrossentropy(), metrics=["accuracy"])
+        mm.fit(K.Dataset.from_tensor_slices((xs, ys)).batch(128), epochs=30, verbose=0)
+        accs[dt] = float(np.mean(mm.predict(xs).argmax(1) == ys.argmax(1)))
+    assert accs["float32"] > 0.9 and abs(accs["float32"] - accs["bfloat16"]) <= 0.03, accs
+    with pytest.raises(ValueError):
+        K.Model(inputs=inp, outputs=o, compute_dtype="float16")
