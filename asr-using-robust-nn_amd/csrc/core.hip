@@ -136,4 +136,24 @@ int lipasr_graph_destroy(lipasr_handle_t h, int id) {
   return LIPASR_OK;
 }
 
+// ------------------------------------------------------------------ CU-masked streams
+int lipasr_stream_create_masked(lipasr_handle_t h, const uint32_t* cu_mask, int n_words, lipasr_stream_t* out) {
+  LP_CHECK_ARG(h && cu_mask && out && n_words >= 1 && n_words <= 64, "lipasr_stream_create_masked: bad argument");
+  bool any = false;
+  for (int i = 0; i < n_words; ++i) any = any || cu_mask[i] != 0;
+  LP_CHECK_ARG(any, "lipasr_stream_create_masked: the mask enables no CU");
+  DeviceGuard g(h->device);
+  hipStream_t st = nullptr;
+  LP_HIP(hipExtStreamCreateWithCUMask(&st, (uint32_t)n_words, cu_mask));
+  *out = st;
+  return LIPASR_OK;
+}
+
+int lipasr_stream_destroy(lipasr_handle_t h, lipasr_stream_t stream) {
+  LP_CHECK_ARG(h && stream, "lipasr_stream_destroy: null argument");
+  DeviceGuard g(h->device);
+  LP_HIP(hipStreamDestroy(static_cast<hipStream_t>(stream)));
+  return LIPASR_OK;
+}
+
 }  // extern "C"

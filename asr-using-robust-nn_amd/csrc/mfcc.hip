@@ -36,6 +36,7 @@ struct MfccPlan {
   int* d_lo = nullptr;       // [n_ptiles]: n_off of each tile's first phase
   int n_ptiles = 0;
   int stage_mask = 0;        // debug/profiling: bit0 skip FFT passes, bit1 skip mel, bit2 use the VALU resampler
+  int rs_target_wgs = 256;   // persistent resampler: workgroups to aim for (one per CU; fewer leaves CUs to the other stream)
   float* d_hann = nullptr;
   float* d_tw = nullptr;  // float2 [2048]
   float* d_twB = nullptr; // float2 [32 r][32 k]: exp(-2 pi i r k / 1024) (pass B of the wave FFT)
@@ -1043,7 +1044,7 @@ static int launch_resample(const MfccPlan* p, const float* wav, int batch, float
       attr_set = true;
     }
     const int tiles = (batch + 31) / 32;
-    int n_ranges = 256 / (tiles > 0 ? tiles : 1);  // aim at one workgroup per CU
+    int n_ranges = p->rs_target_wgs / (tiles > 0 ? tiles : 1);  // aim at one workgroup per CU
     if (n_ranges < 1) n_ranges = 1;
     if (n_ranges > nq) n_ranges = nq;
     hipLaunchKernelGGL(resample_persist_kernel, dim3(n_ranges, tiles), dim3(64 * n_waves), lds, st, wav, p->n_samp, batch, y,
@@ -1349,8 +1350,13 @@ int lipasr_add_noise_f32(lipasr_handle_t h, float* y, int batch, int n, int mode
  * resampler instead of the MFMA one).  Masks 1 and 2 give wrong results by design. */
 int lipasr_debug_set(lipasr_handle_t h, int key, int value) {
   LP_CHECK_ARG(h != nullptr, "lipasr_debug_set: null handle");
-  LP_CHECK_ARG(key == 0, "lipasr_debug_set: unknown key %d", key);
+  LP_CHECK_ARG(key == 0 || key == 1, "lipasr_debug_set: unknown key %d", key);
   if (!h->mfcc) { set_error("lipasr_debug_set: call lipasr_mfcc_plan first"); return LIPASR_ESTATE; }
+  if (key == 1) {
+    LP_CHECK_ARG(value >= 1 && value <= 4096, "lipasr_debug_set: resampler workgroup target %d", value);
+    h->mfcc->rs_target_wgs = value;
+    return LIPASR_OK;
+  }
   h->mfcc->stage_mask = value;
   return LIPASR_OK;
 }

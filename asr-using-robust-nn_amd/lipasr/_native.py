@@ -58,6 +58,8 @@ PROTOTYPES = {
     "lipasr_graph_begin": (i32, [c_h, c_s]),
     "lipasr_graph_end": (i32, [c_h, c_s, PI]),
     "lipasr_graph_launch": (i32, [c_h, i32, c_s]),
+    "lipasr_stream_create_masked": (i32, [c_h, C.POINTER(C.c_uint32), i32, C.POINTER(c_s)]),
+    "lipasr_stream_destroy": (i32, [c_h, c_s]),
     "lipasr_graph_destroy": (i32, [c_h, i32]),
     "lipasr_sigma_max": (i32, [c_h, c_f, i32, i32, c_f, i32, i32, i32, c_f, c_s]),
     "lipasr_project_per_layer": (i32, [c_h, PV, PI, PI, i32, f32, c_f, i32, i32, c_f, c_s]),

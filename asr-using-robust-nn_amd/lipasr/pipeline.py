@@ -26,12 +26,14 @@ from .parallel import DataParallel
 
 class TrainPipeline:
     def __init__(self, model, batch, sr_in=16000, n_samp=16000, utterance_length=44, rho=0.1, constraint="product",
-                 affine=None, pgd=None, dp=None, use_graph=True, per_layer_iters=4, extractor=None):
+                 affine=None, pgd=None, dp=None, use_graph=True, per_layer_iters=4, extractor=None, mfcc_cus="auto"):
         """constraint: 'product' (simple_norm_constraint, all layers), 'per_layer' (norm_constraint) or None.
         affine: (mean, scale) float64 device tensors [20*utterance_length] or None.
         pgd: dict(eps=, eps_step=, max_iter=) for adversarial training on the standardised features.
         extractor: a feature extractor ``f(waves, mean, scale, out=)`` replacing the 2048/512 MFCC plan, e.g.
-        ``speaker_recognition.WindowMfcc`` (441/220 windows -> 2020 features; pass utterance_length=101)."""
+        ``speaker_recognition.WindowMfcc`` (441/220 windows -> 2020 features; pass utterance_length=101).
+        mfcc_cus: how many of the GPU's CUs the feature-extraction stream may use (a CU-masked HIP stream, spread
+        evenly over the XCDs); "auto" = the measured best share, None / 0 = no mask."""
         self.model, self.batch, self.L = model, int(batch), int(utterance_length)
         self.dev = model._device
         self.h = N.get_handle(self.dev.index)
@@ -57,11 +59,45 @@ class TrainPipeline:
         self._order = N.int_array(list(range(nl)))
         self._warm = False
         self.stream = torch.cuda.Stream(device=self.dev)       # training stream (equal priorities measured best)
-        self.mfcc_stream = torch.cuda.Stream(device=self.dev)  # feature-extraction stream
+        self.mfcc_stream = self._make_mfcc_stream(mfcc_cus)   # feature-extraction stream
         self._ev_feat = [torch.cuda.Event() for _ in range(self._nbuf)]   # features of buffer b are ready
         self._ev_free = [None] * self._nbuf                             # training has finished reading buffer b
         self._i = 0
         self._graphs = {}
+
+    def _make_mfcc_stream(self, mfcc_cus):
+        """The MFCC kernels are throughput kernels with thousands of workgroups; the classifier step is a chain of ~30
+        short dependent kernels.  Sharing every CU, the chain's workgroups queue behind MFCC workgroups for LDS and
+        wave slots and the step stretches.  A CU-masked stream keeps the MFCC work on part of the chip: it runs
+        slower there, but it is off the critical path, and the chain finds the other CUs free."""
+        import os
+
+        n_cu = torch.cuda.get_device_properties(self.dev).multi_processor_count
+        if mfcc_cus == "auto":
+            # measured at per-GPU batch 1024 on MI355X: 0.591 ms per step unmasked, 0.549 / 0.529 / 0.518 / 0.513 / 0.510 /
+            # 0.506 / 0.532 / 0.528 with 240 / 224 / 208 / 192 / 176 / 160 / 144 / 128 CUs for the MFCC stream
+            env = os.environ.get("LIPASR_MFCC_CUS")
+            mfcc_cus = int(env) if env is not None else (n_cu * 5) // 8
+        if not mfcc_cus or mfcc_cus >= n_cu:
+            return torch.cuda.Stream(device=self.dev)
+        # Measured on MI355X (scratch/cu_mask_probe.py): mask bits act in groups of 8 consecutive bits -- group g
+        # (bits 8g .. 8g+7) stands for CU g of every XCD, and the group is enabled when any of its bits is set.  So the
+        # share is granted in steps of 8 CUs (one per XCD).
+        n_groups = max(1, n_cu // 8)
+        k = max(1, min(int(round(int(mfcc_cus) / 8)), n_groups))
+        words = (n_cu + 31) // 32
+        mask = (C.c_uint32 * words)()
+        # the first k groups: an evenly spread choice of groups measured erratic (0.517 ... 0.78 ms), the prefix smooth
+        for g in range(k):
+            for b in range(8 * g, 8 * g + 8):
+                mask[b // 32] |= 1 << (b % 32)
+        self.mfcc_cus = 8 * k
+        st = N.c_s()
+        N.check(N.lib.lipasr_stream_create_masked(self.h.h, mask, words, C.byref(st)))
+        self._masked_stream = st
+        # the persistent resampler sizes its grid to one workgroup per CU it may use
+        N.check(N.lib.lipasr_debug_set(self.h.h, 1, self.mfcc_cus))
+        return torch.cuda.ExternalStream(st.value, device=self.dev)
 
     # ---- pieces (all enqueue on the current stream)
     def _attack_and_train(self, bsz, b):

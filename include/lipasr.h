@@ -69,6 +69,13 @@ int lipasr_graph_end(lipasr_handle_t h, lipasr_stream_t stream, int* graph_id);
 int lipasr_graph_launch(lipasr_handle_t h, int graph_id, lipasr_stream_t stream);
 int lipasr_graph_destroy(lipasr_handle_t h, int graph_id);
 
+/* A HIP stream restricted to the CUs whose bits are set in cu_mask (HOST array of n_words 32-bit words, bit i of
+ * word w = CU 32 w + i; hipExtStreamCreateWithCUMask).  The end-to-end step runs the MFCC kernels and the
+ * classifier's many short dependent kernels on two streams; confining the MFCC stream to part of the chip keeps the
+ * rest free for the latency-bound chain (DESIGN.md, step level).  Destroy with lipasr_stream_destroy. */
+int lipasr_stream_create_masked(lipasr_handle_t h, const uint32_t* cu_mask, int n_words, lipasr_stream_t* out);
+int lipasr_stream_destroy(lipasr_handle_t h, lipasr_stream_t stream);
+
 /* ------------------------------------------------------------------ K3: Lipschitz projections
  * Ws: HOST array of n_layers DEVICE pointers to Dense kernels W_l (rows[l] x cols[l], row-major,
  * rows = in, cols = out).  Scalars come back in DEVICE memory (no host sync). */
