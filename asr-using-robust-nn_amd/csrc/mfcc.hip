@@ -483,6 +483,17 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(StftArgs a) {
   const int f0 = fp * 2, f1 = f0 + 1;
   const bool has1 = f1 < a.n_frames;
   const float* yu = a.y + (size_t)u * a.n_y;
+  // per-thread constants of the mel stage (L2-resident tables) start their trip now, not after the FFT's last barrier
+  const int mel_m = tid & 127;
+  const int mst = a.mel_start[mel_m], mln = a.mel_len[mel_m];
+  const int mst2 = (mel_m > 0) ? a.mel_start[mel_m - 1] : 0, mln2 = (mel_m > 0) ? a.mel_len[mel_m - 1] : 0;
+  float mwl[5], mwh[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int k = tid + 256 * i;
+    mwl[i] = (k <= 1024) ? a.mel_wlo[k] : 0.0f;
+    mwh[i] = (k <= 1024) ? a.mel_whi[k] : 0.0f;
+  }
   // frame f covers padded positions [512 f, 512 f + 2048) = y positions [512 f - 1024, ...)
   cpx x0[8];
 #pragma unroll
@@ -530,7 +541,7 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(StftArgs a) {
       const float x0r = 0.5f * (zr + wr), x0i = 0.5f * (zi + wi);
       const float x1r = 0.5f * (zi - wi), x1i = -0.5f * (zr - wr);
       const float p0 = x0r * x0r + x0i * x0i, p1 = x1r * x1r + x1i * x1i;
-      const float wl = a.mel_wlo[k], wh = a.mel_whi[k];
+      const float wl = mwl[i], wh = mwh[i];
       const int pk = k + (k >> 5);  // runs of neighbouring mels start ~32 bins apart at the top of the band
       T[pk] = wl * p0;
       T[kTStride + pk] = wh * p0;
@@ -544,12 +555,10 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(StftArgs a) {
   const float* T2 = T1 + kTStride;
   float s = 0.0f;
   if (!(a.stage_mask & 2)) {
-    const int st = a.mel_start[m], ln = a.mel_len[m];
-    for (int i = 0; i < ln; ++i) { const int b = st + i; s += T1[b + (b >> 5)]; }
+    for (int i = 0; i < mln; ++i) { const int b = mst + i; s += T1[b + (b >> 5)]; }
     if (m > 0) {
-      const int st2 = a.mel_start[m - 1], ln2 = a.mel_len[m - 1];
       float s2 = 0.0f;
-      for (int i = 0; i < ln2; ++i) { const int b = st2 + i; s2 += T2[b + (b >> 5)]; }
+      for (int i = 0; i < mln2; ++i) { const int b = mst2 + i; s2 += T2[b + (b >> 5)]; }
       s += s2;
     }
   } else {
