@@ -93,7 +93,12 @@ class TrainPipeline:
                 mask[b // 32] |= 1 << (b % 32)
         self.mfcc_cus = 8 * k
         st = N.c_s()
-        N.check(N.lib.lipasr_stream_create_masked(self.h.h, mask, words, C.byref(st)))
+        rc = N.lib.lipasr_stream_create_masked(self.h.h, mask, words, C.byref(st))
+        if rc != N.OK:  # a runtime without CU masking: same results, the shared-CU schedule
+            import warnings
+
+            warnings.warn(f"lipasr: CU-masked stream unavailable ({N.last_error()}); the MFCC stream shares every CU")
+            return torch.cuda.Stream(device=self.dev)
         self._masked_stream = st
         # the persistent resampler sizes its grid to one workgroup per CU it may use
         N.check(N.lib.lipasr_debug_set(self.h.h, 1, self.mfcc_cus))
