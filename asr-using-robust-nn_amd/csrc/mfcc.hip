@@ -250,15 +250,20 @@ constexpr int kRpMaxWaves = 16;
 
 __global__ __launch_bounds__(64 * kRpMaxWaves) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void resample_persist_kernel(const float* __restrict__ x, int n_samp, int batch, float* __restrict__ y, int n_valid, int n_y,
-                             int up, int down, int left, int nq, const float* __restrict__ Hband,
+                             int up, int down, int left, int nq, int n_tiles, const float* __restrict__ Hband,
                              const int* __restrict__ lo) {
   extern __shared__ __attribute__((aligned(16))) float xs2[];  // [2][32][kRsStride]
   const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // = phase tile
   const int li = lane & 31, h = lane >> 5;
-  const int n_ranges = gridDim.x;
-  const int q_begin = (int)(((long)blockIdx.x * nq) / n_ranges), q_end = (int)(((long)(blockIdx.x + 1) * nq) / n_ranges);
-  const int u0 = blockIdx.y * 32;
+  // 1-D grid of W workgroups over T clip tiles: tile t gets ceil((t+1) W / T) - ceil(t W / T) of them (so W need not be
+  // a multiple of T: the grid is sized to the CUs this stream may use), each a contiguous share of the tile's q-blocks
+  const int W = gridDim.x, T = n_tiles;
+  const int tile = (int)(((long)blockIdx.x * T) / W);
+  const int first = (int)(((long)tile * W + T - 1) / T), next = (int)(((long)(tile + 1) * W + T - 1) / T);
+  const int n_ranges = next - first, ri = blockIdx.x - first;
+  const int q_begin = (int)(((long)ri * nq) / n_ranges), q_end = (int)(((long)(ri + 1) * nq) / n_ranges);
+  const int u0 = tile * 32;
   constexpr int kVecPerRow = (kRsStride - 1) / 4;   // 120 float4 = 480 floats per row
   constexpr int kFillMax = 5;                        // float4 per thread per window: 3840 over >= 768 threads
   // tap fragments of this wavefront's phase tile: loaded once
@@ -1053,11 +1058,11 @@ static int launch_resample(const MfccPlan* p, const float* wav, int batch, float
       attr_set = true;
     }
     const int tiles = (batch + 31) / 32;
-    int n_ranges = p->rs_target_wgs / (tiles > 0 ? tiles : 1);  // aim at one workgroup per CU
-    if (n_ranges < 1) n_ranges = 1;
-    if (n_ranges > nq) n_ranges = nq;
-    hipLaunchKernelGGL(resample_persist_kernel, dim3(n_ranges, tiles), dim3(64 * n_waves), lds, st, wav, p->n_samp, batch, y,
-                       p->n_valid, p->n_y, p->up, p->down, p->left, nq, p->d_hband, p->d_lo);
+    int wgs = p->rs_target_wgs;  // one workgroup per CU this stream may use
+    if (wgs < tiles) wgs = tiles;
+    if (wgs > tiles * nq) wgs = tiles * nq;
+    hipLaunchKernelGGL(resample_persist_kernel, dim3(wgs), dim3(64 * n_waves), lds, st, wav, p->n_samp, batch, y,
+                       p->n_valid, p->n_y, p->up, p->down, p->left, nq, tiles, p->d_hband, p->d_lo);
   } else if (p->d_hband && !(p->stage_mask & 4)) {
     const size_t lds = (size_t)32 * kRsStride * sizeof(float);
     static bool attr_set = false;

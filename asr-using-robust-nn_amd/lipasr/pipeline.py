@@ -83,8 +83,10 @@ class TrainPipeline:
         # Measured on MI355X (scratch/cu_mask_probe.py): mask bits act in groups of 8 consecutive bits -- group g
         # (bits 8g .. 8g+7) stands for CU g of every XCD, and the group is enabled when any of its bits is set.  So the
         # share is granted in steps of 8 CUs (one per XCD).
+        # (pairs of settings 32 apart behaved alike -- 240/224, 208/192, 176/160, 144/128 -- so the share is rounded
+        # down to a multiple of 32 CUs, which is what the hardware appears to grant)
         n_groups = max(1, n_cu // 8)
-        k = max(1, min(int(round(int(mfcc_cus) / 8)), n_groups))
+        k = max(4, min((int(mfcc_cus) // 32) * 4, n_groups))
         words = (n_cu + 31) // 32
         mask = (C.c_uint32 * words)()
         # the first k groups: an evenly spread choice of groups measured erratic (0.517 ... 0.78 ms), the prefix smooth
