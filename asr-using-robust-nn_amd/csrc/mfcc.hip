@@ -1157,6 +1157,7 @@ int lipasr_mfcc_plan_ex(lipasr_handle_t h, int sr_in, int n_samp, int batch_max,
   resampled_lengths(n_samp, sr_in, kSr, &p->n_valid, &p->n_y);
   if (p->n_y < 2) { delete p; set_error("lipasr_mfcc_plan: clip too short after resampling"); return LIPASR_EINVAL; }
   p->n_fft = n_fft; p->hop = hop; p->dft = dft;
+  p->rs_target_wgs = h->rs_target_wgs;
   p->n_frames = 1 + p->n_y / hop;
   // the FFT path reflects repeatedly like np.pad (any clip of >= 2 samples); the short-window path's pad kernel
   // reflects once, which needs the clip to be longer than the padding
@@ -1368,6 +1369,7 @@ int lipasr_debug_set(lipasr_handle_t h, int key, int value) {
   if (!h->mfcc) { set_error("lipasr_debug_set: call lipasr_mfcc_plan first"); return LIPASR_ESTATE; }
   if (key == 1) {
     LP_CHECK_ARG(value >= 1 && value <= 4096, "lipasr_debug_set: resampler workgroup target %d", value);
+    h->rs_target_wgs = value;  // kept in the handle: a later lipasr_mfcc_plan inherits it
     h->mfcc->rs_target_wgs = value;
     return LIPASR_OK;
   }

@@ -76,8 +76,10 @@ class TrainPipeline:
         if mfcc_cus == "auto":
             # measured at per-GPU batch 1024 on MI355X: 0.591 ms per step unmasked, 0.549 / 0.529 / 0.518 / 0.513 / 0.510 /
             # 0.506 / 0.532 / 0.528 with 240 / 224 / 208 / 192 / 176 / 160 / 144 / 128 CUs for the MFCC stream
+            # (a heavier extractor wants a larger share: the 441/220 Speaker-recognition path measured 0.904 ms unmasked,
+            # 0.865 / 0.826 / 0.811 with 160 / 192 / 224 CUs)
             env = os.environ.get("LIPASR_MFCC_CUS")
-            mfcc_cus = int(env) if env is not None else (n_cu * 5) // 8
+            mfcc_cus = int(env) if env is not None else ((n_cu * 7) // 8 if self._custom_ex else (n_cu * 5) // 8)
         if not mfcc_cus or mfcc_cus >= n_cu:
             return torch.cuda.Stream(device=self.dev)
         # Measured on MI355X (scratch/cu_mask_probe.py): mask bits act in groups of 8 consecutive bits -- group g

@@ -311,8 +311,10 @@ int lipasr_mfcc_profile_end(lipasr_handle_t h, float* avg_ms3, int* n_calls);
 int lipasr_add_noise_f32(lipasr_handle_t h, float* y, int batch, int n, int mode, float p0, float p1,
                          uint64_t seed, lipasr_stream_t stream);
 
-/* Profiling knob.  key 0: MFCC stage mask (bit0 skip the FFT passes, bit1 skip the mel reduction -- both give
- * wrong results and exist to time the remaining stages; bit2 selects the VALU resampler instead of the MFMA one). */
+/* Knobs.  key 0: MFCC stage mask for profiling (bit0 skip the FFT passes, bit1 skip the mel reduction -- both give
+ * wrong results and exist to time the remaining stages; bit2 selects the VALU resampler instead of the MFMA one).
+ * key 1: number of workgroups the persistent resampler aims for = the CUs its stream may use (default 256; a
+ * pipeline that runs the MFCC on a CU-masked stream sets it to the size of the mask).  Kept in the handle. */
 int lipasr_debug_set(lipasr_handle_t h, int key, int value);
 
 /* Profiling knob: GEMM kernel choice. 0 = automatic, 1 = split-K register kernel only, 2 = LDS-tiled kernel
