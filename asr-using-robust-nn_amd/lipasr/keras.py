@@ -25,6 +25,7 @@ import numpy as np
 import torch
 
 from . import _native as N
+from . import keras_h5
 
 _name_counts = {}
 
@@ -579,7 +580,7 @@ class Model:
         loss, acc = self._evaluate_device(xt, yt, self._max_batch)
         return [loss, acc]
 
-    # ---- checkpoints (HDF5 is unavailable here; a torch archive carries the same state)
+    # ---- checkpoints: Keras' HDF5 layout behind .h5 / .hdf5 names (lipasr.keras_h5), a torch archive otherwise
     def _config(self):
         cfg = []
         for layer in self.layers:
@@ -601,10 +602,61 @@ class Model:
         self._params.copy_(sd["params"]); self._bnstate.copy_(sd["bnstate"])
         self._adam_m.copy_(sd["adam_m"]); self._adam_v.copy_(sd["adam_v"]); self._step.copy_(sd["step"])
 
-    def save(self, path):
+    def _named_weights(self):
+        """[(layer name, [(Keras weight name, host array)])] for every layer, in model order."""
+        out = []
+        for layer in self.layers:
+            kind = type(layer).__name__
+            out.append((layer.name, list(zip(keras_h5.weight_names(kind, layer.name), layer.get_weights()))))
+        return out
+
+    def _trainable_segments(self):
+        """(Keras variable path, offset, count, shape) of the trainable variables in Keras' order (kernel, bias,
+        gamma, beta per block): the order tf.keras' Adam creates its m and v slots in."""
+        segs = []
+        for i, b in enumerate(self._blocks):
+            d = b["dense"]
+            segs.append((f"{d.name}/kernel", *self._segs[(i, N.SEG_W)], (self._widths[i], d.units)))
+            segs.append((f"{d.name}/bias", *self._segs[(i, N.SEG_B)], (d.units,)))
+            if b["bn"] is not None:
+                segs.append((f"{b['bn'].name}/gamma", *self._segs[(i, N.SEG_GAMMA)], (d.units,)))
+                segs.append((f"{b['bn'].name}/beta", *self._segs[(i, N.SEG_BETA)], (d.units,)))
+        return segs
+
+    def _optimizer_weights(self):
+        """tf.keras Adam.weights: iterations, then the m slot of every variable, then the v slots."""
+        m, v = self._adam_m.cpu().numpy(), self._adam_v.cpu().numpy()
+        out = [("Adam/iter:0", np.asarray(int(self._step.item()), dtype=np.int64))]
+        for slot, buf in (("m", m), ("v", v)):
+            for name, off, cnt, shape in self._trainable_segments():
+                out.append((f"Adam/{name}/{slot}:0", buf[off:off + cnt].reshape(shape).copy()))
+        return out
+
+    def _load_optimizer_weights(self, ow):
+        """Slots are matched by name ('Adam/<layer>/<var>/m:0'); a file without them leaves the moments at zero."""
+        if not ow:
+            return
+        it = [a for n, a in ow.items() if n.split("/")[-1].startswith("iter")]
+        if it:
+            self._step.fill_(int(np.asarray(it[0]).reshape(-1)[0]))
+        for name, off, cnt, _ in self._trainable_segments():
+            for slot, buf in (("m", self._adam_m), ("v", self._adam_v)):
+                hit = [a for n, a in ow.items() if n.endswith(f"/{name}/{slot}:0") or n == f"{name}/{slot}:0"]
+                if hit:
+                    buf[off:off + cnt].copy_(torch.as_tensor(np.asarray(hit[0], dtype=np.float32).reshape(-1)))
+
+    def save(self, path, include_optimizer=True):
+        """Model.save / ModelCheckpoint target (train_constraints.py:104-105): '.h5' / '.hdf5' names get Keras' HDF5
+        layout (model_config, model_weights, training_config, optimizer_weights); other names a torch archive."""
         d = os.path.dirname(path)
         if d:
             os.makedirs(d, exist_ok=True)
+        if keras_h5.is_hdf5_path(path):
+            adam = getattr(self, "_adam", None)
+            keras_h5.save_model(path, self._config(), self._named_weights(),
+                                train_cfg=keras_h5.training_config(*adam) if adam else None,
+                                optimizer_weights=self._optimizer_weights() if (adam and include_optimizer) else None)
+            return
         sd = {k: v.cpu() for k, v in self._state_dict().items()}
         torch.save({"config": self._config(), "state": sd, "adam": getattr(self, "_adam", None), "max_batch": self._max_batch}, path)
 
@@ -626,15 +678,41 @@ class Model:
         if i != len(weights):
             raise ValueError(f"set_weights: got {len(weights)} arrays, the model holds {i}")
 
+    def _set_named_weights(self, layers, by_name=False):
+        """layers: [(layer name, [(weight name, array)])] as read from a file.  Keras' default is topological loading:
+        the file's weighted layers are matched, in order, with the model's weighted layers."""
+        mine = [l for l in self.layers if l.get_weights()]
+        theirs = [(n, w) for n, w in layers if w]
+        if by_name:
+            lookup = dict(theirs)
+            for layer in mine:
+                if layer.name in lookup:
+                    layer.set_weights([a for _, a in lookup[layer.name]])
+            return
+        if len(mine) != len(theirs):
+            raise ValueError(f"the file holds weights for {len(theirs)} layers, the model has {len(mine)} layers with weights")
+        for layer, (lname, ws) in zip(mine, theirs):
+            want = [w.shape for w in layer.get_weights()]
+            got = [np.asarray(a).shape for _, a in ws]
+            if want != got:
+                raise ValueError(f"layer {layer.name} <- file layer {lname}: weight shapes {got} do not match {want}")
+            layer.set_weights([a for _, a in ws])
+
     def save_weights(self, path):
         """Weights only (train_constraints.py:96's commented ``load_weights`` counterpart): the trainable and
-        BatchNorm state, no optimizer moments."""
+        BatchNorm state, no optimizer moments.  '.h5' / '.hdf5' names get Keras' HDF5 weights layout."""
         d = os.path.dirname(path)
         if d:
             os.makedirs(d, exist_ok=True)
+        if keras_h5.is_hdf5_path(path):
+            keras_h5.save_weights(path, self._named_weights())
+            return
         torch.save({"config": self._config(), "weights": [np.asarray(w) for w in self.get_weights()]}, path)
 
-    def load_weights(self, path):
+    def load_weights(self, path, by_name=False):
+        if _is_hdf5_file(path):
+            self._set_named_weights(keras_h5.load_weights(path), by_name=by_name)
+            return
         blob = torch.load(path, map_location="cpu", weights_only=False)
         if "weights" in blob:
             self.set_weights(blob["weights"])
@@ -642,6 +720,12 @@ class Model:
             sd = blob["state"]
             self._params.copy_(sd["params"].to(self._device))
             self._bnstate.copy_(sd["bnstate"].to(self._device))
+
+
+def _is_hdf5_file(path):
+    """By content, not by name: the 8-byte HDF5 signature."""
+    with open(path, "rb") as fh:
+        return fh.read(8) == b"\x89HDF\r\n\x1a\n"
 
 
 def model_from_config(cfg, **kw):
@@ -660,10 +744,23 @@ def model_from_config(cfg, **kw):
     return Model(inputs=inp, outputs=node, **kw)
 
 
-def load_model(path, custom_objects=None):
-    """tensorflow.keras.models.load_model for archives written by Model.save (train_constraints.py:107)."""
+def load_model(path, custom_objects=None, compile=True, **kw):
+    """tensorflow.keras.models.load_model (train_constraints.py:107, attacks.py:315-317): Keras' own ``.h5`` files and
+    the archives Model.save writes.  ``custom_objects`` is accepted for signature parity; NonNeg is the one
+    constraint class a checkpoint of the path carries."""
+    if _is_hdf5_file(path):
+        blob = keras_h5.load_model(path)
+        m = model_from_config(blob["chain"], **kw)
+        m._set_named_weights(blob["layers"])
+        if compile and blob["adam"]:
+            lr, b1, b2, eps = blob["adam"]
+            m.compile(optimizer="adam", loss=CategoricalCrossentropy(), metrics=["accuracy"], learning_rate=lr, beta_1=b1,
+                      beta_2=b2, epsilon=eps)
+            m._load_optimizer_weights(blob["optimizer_weights"])
+        return m
     blob = torch.load(path, map_location="cpu", weights_only=False)
-    m = model_from_config(blob["config"], max_batch=blob.get("max_batch", 1024))
+    kw.setdefault("max_batch", blob.get("max_batch", 1024))
+    m = model_from_config(blob["config"], **kw)
     m._load_state_dict({k: v.to(m._device) for k, v in blob["state"].items()})
     if blob.get("adam"):
         lr, b1, b2, eps = blob["adam"]

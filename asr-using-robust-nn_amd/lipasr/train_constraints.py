@@ -104,8 +104,8 @@ def main(argv=None):
               callbacks=[EarlyStopping(monitor="val_loss", patience=6000, restore_best_weights=False),
                          simple_norm_constraint(rho=args.rho, affected_layers_indices=[]),
                          lip_stats_callback(),
-                         ModelCheckpoint("bin/models_constrained/TEST.pt", save_best_only=True, verbose=1)])
-    model = load_model("bin/models_constrained/TEST.pt")
+                         ModelCheckpoint("bin/models_constrained/TEST.h5", save_best_only=True, verbose=1)])
+    model = load_model("bin/models_constrained/TEST.h5")
     y = np.argmax(model.predict(test_data), axis=1)
     results = model.evaluate(test_data, test_label)
     print(f"Test loss: {results[0]} / Test accuracy: {results[1]} / agreement {np.mean(y == test_label1)}")

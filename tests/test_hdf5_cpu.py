@@ -1,0 +1,259 @@
+"""Keras' ``.h5`` checkpoint layout (train_constraints.py:104-107, train_google_dataset.py:85-87, attacks.py:315-317)
+through lipasr's ctypes binding to libhdf5 -- host-side file-format code, no GPU.
+
+The binding is checked against an INDEPENDENT HDF5 implementation where the image offers one: h5py under
+/opt/conda/bin/python3.9, driven as a separate process by tests/h5py_peer.py (lipasr never imports h5py).  It reads
+our files the way Keras' loader walks them, and writes files the way tf.keras 2.x + h5py 2.x wrote them (bytes
+attributes, 'Sequential' configs, the old 'lr' key) for our reader.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PEER_PY = os.environ.get("LIPASR_H5PY_PYTHON", "/opt/conda/bin/python3.9")
+
+
+def _hdf5():
+    from lipasr import _hdf5 as H
+
+    try:
+        H.library()
+    except H.HDF5Error as e:
+        pytest.skip(f"no libhdf5 in this image: {e}")
+    return H
+
+
+def _peer(*args):
+    if not os.path.exists(PEER_PY):
+        pytest.skip("no second interpreter with h5py in this image")
+    probe = subprocess.run([PEER_PY, "-W", "ignore", "-c", "import h5py"], capture_output=True)
+    if probe.returncode != 0:
+        pytest.skip("the second interpreter has no h5py")
+    env = {k: v for k, v in os.environ.items() if not k.startswith("PYTHON")}
+    r = subprocess.run([PEER_PY, "-W", "ignore", os.path.join(HERE, "h5py_peer.py"), *args], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+
+
+CHAIN = [("Input", 24, "input_1"), ("Dense", 16, "relu", True, "dense"), ("BatchNormalization", "batch_normalization"),
+         ("Dropout", 0.1, "dropout"), ("Dense", 8, "relu", True, "dense_1"), ("BatchNormalization", "batch_normalization_1"),
+         ("Dense", 5, "softmax", True, "dense_2")]
+
+
+def _weights(rng):
+    from lipasr import keras_h5 as KH
+
+    layers, widths, w_in = [], {}, None
+    for item in CHAIN:
+        kind, name = item[0], item[-1]
+        arrs = []
+        if kind == "Input":
+            w_in = item[1]
+        elif kind == "Dense":
+            arrs = [rng.standard_normal((w_in, item[1])).astype(np.float32), rng.standard_normal(item[1]).astype(np.float32)]
+            w_in = item[1]
+        elif kind == "BatchNormalization":
+            arrs = [rng.standard_normal(w_in).astype(np.float32) for _ in range(4)]
+        layers.append((name, list(zip(KH.weight_names(kind, name), arrs))))
+    return layers
+
+
+def _optimizer(layers, rng):
+    out = [("Adam/iter:0", np.asarray(137, dtype=np.int64))]
+    for slot in ("m", "v"):
+        for _, ws in layers:
+            for wname, a in ws:
+                if "moving" in wname:
+                    continue
+                out.append((f"Adam/{wname[:-2]}/{slot}:0", rng.standard_normal(a.shape).astype(np.float32)))
+    return out
+
+
+def test_binding_round_trip(tmp_path):
+    H = _hdf5()
+    p = str(tmp_path / "t.h5")
+    big = np.random.default_rng(0).standard_normal((1300, 1024)).astype(np.float32)
+    with H.File(p, "w") as f:
+        f.write_dataset("a/b/kernel:0", big)
+        f.write_dataset("a/scalar", np.asarray(7, dtype=np.int64))
+        f.write_dataset("a/empty", np.zeros((0, 3), dtype=np.float64))
+        f.write_attr("/", "text", 'json {"k": "v"} \u00fc\u00df')
+        f.write_attr("a", "names", [b"x", b"longer/name:0", "str"])
+        f.write_attr("a", "none", [])
+        f.write_attr("a/b", "num", np.arange(3, dtype=np.int32))
+        f.write_attr("a/b", "pi", np.float64(3.25))
+    with open(p, "rb") as fh:
+        assert fh.read(8) == b"\x89HDF\r\n\x1a\n"
+    with H.File(p) as f:
+        np.testing.assert_array_equal(f.read_dataset("a/b/kernel:0"), big)
+        s = f.read_dataset("a/scalar")
+        assert s.shape == () and s.dtype == np.int64 and int(s) == 7
+        assert f.read_dataset("a/empty").shape == (0, 3)
+        assert f.read_attr("/", "text") == 'json {"k": "v"} \u00fc\u00df'
+        assert f.read_attr("a", "names") == ["x", "longer/name:0", "str"]
+        none = f.read_attr("a", "none")
+        assert isinstance(none, np.ndarray) and none.size == 0
+        np.testing.assert_array_equal(f.read_attr("a/b", "num"), [0, 1, 2])
+        assert f.read_attr("a/b", "pi") == 3.25
+        assert f.exists("a/b/kernel:0") and not f.exists("a/c/kernel:0") and f.has_attr("a", "names") and not f.has_attr("a", "nope")
+        with pytest.raises(H.HDF5Error):
+            f.read_dataset("a/missing")
+    with pytest.raises(FileNotFoundError):
+        H.File(str(tmp_path / "absent.h5"))
+    junk = tmp_path / "junk.h5"
+    junk.write_bytes(b"not hdf5 at all")
+    with pytest.raises(H.HDF5Error):
+        H.File(str(junk))
+
+
+def test_keras_layout_round_trip(tmp_path):
+    _hdf5()
+    from lipasr import keras_h5 as KH
+
+    rng = np.random.default_rng(1)
+    layers = _weights(rng)
+    opt = _optimizer(layers, rng)
+    p = str(tmp_path / "model.h5")
+    KH.save_model(p, CHAIN, layers, train_cfg=KH.training_config(2e-3, 0.8, 0.95, 1e-6), optimizer_weights=opt)
+    blob = KH.load_model(p)
+    assert blob["chain"] == CHAIN
+    assert blob["adam"] == (2e-3, 0.8, 0.95, 1e-6)
+    assert [n for n, _ in blob["layers"]] == [c[-1] for c in CHAIN]
+    for (n0, w0), (n1, w1) in zip(layers, blob["layers"]):
+        assert [a for a, _ in w0] == [a for a, _ in w1]
+        for (_, a), (_, b) in zip(w0, w1):
+            np.testing.assert_array_equal(a, b)
+    assert set(blob["optimizer_weights"]) == {n for n, _ in opt}
+    for n, a in opt:
+        np.testing.assert_array_equal(blob["optimizer_weights"][n], a)
+    assert blob["optimizer_weights"]["Adam/iter:0"].dtype == np.int64
+    # weights-only file, and load_weights pointed at a full-model file
+    pw = str(tmp_path / "weights.h5")
+    KH.save_weights(pw, layers)
+    for src in (pw, p):
+        got = KH.load_weights(src)
+        for (n0, w0), (n1, w1) in zip(layers, got):
+            assert n0 == n1 and len(w0) == len(w1)
+            for (_, a), (_, b) in zip(w0, w1):
+                np.testing.assert_array_equal(a, b)
+    with pytest.raises(ValueError):
+        KH.load_model(pw)
+
+
+def test_model_config_is_what_keras_writes():
+    """Functional config of the reference's network (train_constraints.py:63-88): field by field what tf.keras 2.x
+    serialises for Input / Dense(NonNeg) / BatchNormalization / Dropout, and our own parser inverts it."""
+    from lipasr import keras_h5 as KH
+
+    cfg = KH.model_config(CHAIN)
+    assert cfg["class_name"] == "Functional"
+    ls = cfg["config"]["layers"]
+    assert [l["class_name"] for l in ls] == ["InputLayer", "Dense", "BatchNormalization", "Dropout", "Dense", "BatchNormalization", "Dense"]
+    assert ls[0]["config"]["batch_input_shape"] == [None, 24] and ls[0]["inbound_nodes"] == []
+    assert ls[1]["inbound_nodes"] == [[["input_1", 0, 0, {}]]]
+    assert ls[1]["config"]["kernel_constraint"] == {"class_name": "NonNeg", "config": {}}
+    assert ls[2]["config"]["momentum"] == 0.99 and ls[2]["config"]["epsilon"] == 0.001 and ls[2]["config"]["axis"] == [1]
+    assert ls[3]["config"]["rate"] == 0.1
+    assert cfg["config"]["input_layers"] == [["input_1", 0, 0]] and cfg["config"]["output_layers"] == [["dense_2", 0, 0]]
+    assert KH.chain_from_config(json.dumps(cfg)) == CHAIN
+    # rejected: what the kernels do not implement
+    bad = json.loads(json.dumps(cfg))
+    bad["config"]["layers"][2]["config"]["epsilon"] = 1e-5
+    with pytest.raises(NotImplementedError):
+        KH.chain_from_config(bad)
+    bad = json.loads(json.dumps(cfg))
+    bad["config"]["layers"][1]["config"]["kernel_constraint"] = {"class_name": "customConstraint", "config": {"rho": 1}}
+    with pytest.raises(NotImplementedError):
+        KH.chain_from_config(bad)
+    bad = json.loads(json.dumps(cfg))
+    bad["config"]["layers"][1]["class_name"] = "Conv1D"
+    with pytest.raises(NotImplementedError):
+        KH.chain_from_config(bad)
+
+
+def test_h5py_reads_our_file_like_keras(tmp_path):
+    _hdf5()
+    from lipasr import keras_h5 as KH
+
+    rng = np.random.default_rng(2)
+    layers = _weights(rng)
+    opt = _optimizer(layers, rng)
+    p, out = str(tmp_path / "model.h5"), str(tmp_path / "dump.npz")
+    KH.save_model(p, CHAIN, layers, train_cfg=KH.training_config(1e-3, 0.9, 0.999, 1e-7), optimizer_weights=opt)
+    _peer("read", p, out)
+    d = np.load(out)
+    assert str(d["keras_version"]) == KH.KERAS_VERSION and str(d["backend"]) == "tensorflow"
+    assert json.loads(str(d["model_config"])) == KH.model_config(CHAIN)
+    assert json.loads(str(d["training_config"]))["optimizer_config"]["config"]["learning_rate"] == 1e-3
+    assert json.loads(str(d["layer_names"])) == [c[-1] for c in CHAIN]
+    wn = json.loads(str(d["weight_names"]))
+    for lname, ws in layers:
+        assert wn[lname] == [n for n, _ in ws]
+        for n, a in ws:
+            got = d[f"w:{lname}:{n}"]
+            assert got.dtype == np.float32
+            np.testing.assert_array_equal(got, a)
+    assert json.loads(str(d["optimizer_weight_names"])) == [n for n, _ in opt]
+    for n, a in opt:
+        np.testing.assert_array_equal(d[f"o:{n}"], a)
+
+
+def test_we_read_a_file_written_the_keras_way(tmp_path):
+    """tf.keras 2.x + h5py 2.x habits: JSON attributes as bytes, a Sequential config whose first Dense carries
+    batch_input_shape, 'lr' instead of 'learning_rate', float64 empty weight_names for Dropout."""
+    _hdf5()
+    from lipasr import keras_h5 as KH
+
+    rng = np.random.default_rng(3)
+    seq_layers = [
+        {"class_name": "Dense", "config": {"name": "dense_7", "trainable": True, "batch_input_shape": [None, 12], "dtype": "float32",
+                                           "units": 6, "activation": "relu", "use_bias": True, "kernel_constraint": None}},
+        {"class_name": "Dropout", "config": {"name": "dropout_3", "rate": 0.4, "noise_shape": None, "seed": None}},
+        {"class_name": "Dense", "config": {"name": "dense_8", "units": 3, "activation": "softmax", "use_bias": True,
+                                           "kernel_constraint": {"class_name": "NonNeg", "config": {}}}},
+    ]
+    names = ["dense_7", "dropout_3", "dense_8"]
+    wn = {"dense_7": ["dense_7/kernel:0", "dense_7/bias:0"], "dropout_3": [], "dense_8": ["dense_8/kernel:0", "dense_8/bias:0"]}
+    arrs = {"w:dense_7:dense_7/kernel:0": rng.standard_normal((12, 6)).astype(np.float32),
+            "w:dense_7:dense_7/bias:0": rng.standard_normal(6).astype(np.float32),
+            "w:dense_8:dense_8/kernel:0": rng.standard_normal((6, 3)).astype(np.float32),
+            "w:dense_8:dense_8/bias:0": rng.standard_normal(3).astype(np.float32)}
+    on = ["Adam/iter:0", "Adam/dense_7/kernel/m:0", "Adam/dense_7/kernel/v:0"]
+    arrs["o:Adam/iter:0"] = np.asarray(41, dtype=np.int64)
+    arrs["o:Adam/dense_7/kernel/m:0"] = rng.standard_normal((12, 6)).astype(np.float32)
+    arrs["o:Adam/dense_7/kernel/v:0"] = rng.random((12, 6)).astype(np.float32)
+    spec = {"keras_version": "2.2.4-tf", "model_config": {"class_name": "Sequential", "config": {"name": "sequential", "layers": seq_layers}},
+            "training_config": {"loss": "categorical_crossentropy", "metrics": ["accuracy"],
+                                "optimizer_config": {"class_name": "Adam", "config": {"lr": 0.01, "beta_1": 0.9, "beta_2": 0.999,
+                                                                                       "epsilon": 1e-07, "amsgrad": False}}},
+            "layer_names": names, "weight_names": wn, "optimizer_weight_names": on}
+    src, p = str(tmp_path / "spec.npz"), str(tmp_path / "keras.h5")
+    np.savez(src, spec=json.dumps(spec), **arrs)
+    _peer("write", p, src)
+    blob = KH.load_model(p)
+    assert blob["chain"] == [("Input", 12, "dense_7_input"), ("Dense", 6, "relu", False, "dense_7"), ("Dropout", 0.4, "dropout_3"),
+                             ("Dense", 3, "softmax", True, "dense_8")]
+    assert blob["adam"] == (0.01, 0.9, 0.999, 1e-7)
+    got = dict(blob["layers"])
+    assert got["dropout_3"] == []
+    for ln in ("dense_7", "dense_8"):
+        assert [n for n, _ in got[ln]] == wn[ln]
+        for n, a in got[ln]:
+            np.testing.assert_array_equal(a, arrs[f"w:{ln}:{n}"])
+    assert int(blob["optimizer_weights"]["Adam/iter:0"]) == 41
+    np.testing.assert_array_equal(blob["optimizer_weights"]["Adam/dense_7/kernel/v:0"], arrs["o:Adam/dense_7/kernel/v:0"])
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    """No substitute format hides behind an .h5 name: without libhdf5 the call raises."""
+    code = ("import os, sys; sys.path.insert(0, sys.argv[1]); os.environ['LIPASR_HDF5_LIBRARY'] = '/nonexistent/libhdf5.so';"
+            "import ctypes.util as U; U.find_library = lambda n: None;"
+            "from lipasr import _hdf5 as H; H._SEARCH = ();\n"
+            "try:\n    H.File(sys.argv[2], 'w'); print('opened')\nexcept H.HDF5Error as e:\n    print('raised', 'libhdf5 not found' in str(e))")
+    r = subprocess.run([sys.executable, "-c", code, os.path.join(os.path.dirname(HERE), "asr-using-robust-nn_amd"), str(tmp_path / "x.h5")],
+                       capture_output=True, text=True)
+    assert r.stdout.strip() == "raised True", r.stdout + r.stderr

@@ -256,6 +256,62 @@ def test_weight_io_and_tensorboard_callback(cuda, tmp_path):
     assert [l["epoch"] for l in lines] == [0, 1, 2] and all("loss" in l for l in lines)
 
 
+def test_keras_h5_checkpoint(cuda, tmp_path):
+    """ModelCheckpoint('...TEST.h5') -> load_model (train_constraints.py:104-107): the .h5 file is Keras' HDF5 layout.
+    A reloaded model predicts bit-identically AND resumes training bit-identically (Adam iterations, m and v come
+    back from optimizer_weights); save_weights/load_weights go through the same format."""
+    from lipasr import _hdf5 as H
+    from lipasr import keras as K
+
+    spec = [P.LayerSpec(24, 16, True, 0.0, True), P.LayerSpec(16, 8, True, 0.0, True), P.LayerSpec(8, 5, False, 0.0, True)]
+    m = build_model(spec, max_batch=32, seed=7)
+    m.compile(optimizer="adam", loss=K.CategoricalCrossentropy(), metrics=["accuracy"], learning_rate=3e-3)
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((32, 24)).astype(np.float32)
+    y = P.to_categorical(np.arange(32) % 5, 5)
+    xt, yt = dev(x), dev(y)
+    for _ in range(3):
+        m.train_on_batch(xt, yt, dropout=False)
+    path = str(tmp_path / "bin" / "models_constrained" / "TEST.h5")
+    m.save(path)
+    with open(path, "rb") as fh:
+        assert fh.read(8) == b"\x89HDF\r\n\x1a\n"
+    with H.File(path) as f:
+        names = f.read_attr("model_weights", "layer_names")
+        assert names == [l.name for l in m.layers]
+        d0 = [l for l in m.layers if "dense" in l.name][0]
+        np.testing.assert_array_equal(f.read_dataset(f"model_weights/{d0.name}/{d0.name}/kernel:0"), d0.get_weights()[0])
+        assert int(f.read_dataset("optimizer_weights/Adam/iter:0")) == 3
+    m2 = K.load_model(path, max_batch=32)
+    assert [type(l).__name__ for l in m2.layers] == [type(l).__name__ for l in m.layers]
+    assert m2._adam == m._adam
+    np.testing.assert_array_equal(m2.predict(x), m.predict(x))
+    for _ in range(2):
+        m.train_on_batch(xt, yt, dropout=False)
+        m2.train_on_batch(xt, yt, dropout=False)
+    assert int(m2._step.item()) == 5
+    np.testing.assert_array_equal(m2._params.cpu().numpy(), m._params.cpu().numpy())
+    np.testing.assert_array_equal(m2._bnstate.cpu().numpy(), m._bnstate.cpu().numpy())
+    # weights-only .h5, into a differently initialised model; and load_weights pointed at the full-model file
+    wpath = str(tmp_path / "w.h5")
+    m.save_weights(wpath)
+    for src in (wpath, path):
+        m3 = build_model(spec, max_batch=32, seed=9)
+        m3.load_weights(src)
+        if src == wpath:
+            np.testing.assert_array_equal(m3.predict(x), m.predict(x))
+        else:
+            np.testing.assert_array_equal(m3.predict(x), K.load_model(path, max_batch=32).predict(x))
+    wrong = build_model([P.LayerSpec(24, 16, True, 0.0, True), P.LayerSpec(16, 5, False, 0.0, True)], max_batch=32)
+    with pytest.raises(ValueError):
+        wrong.load_weights(wpath)
+    # the callback the reference passes to fit()
+    ck = str(tmp_path / "ck" / "best.h5")
+    m.fit(K.Dataset.from_tensor_slices((x, y)).batch(16), epochs=2, validation_data=K.Dataset.from_tensor_slices((x, y)).batch(16),
+          verbose=0, callbacks=[K.ModelCheckpoint(ck, save_best_only=True)])
+    assert K.load_model(ck, max_batch=32).predict(x).shape == (32, 5)
+
+
 def test_bf16_operand_mode(cuda):
     """lipasr_mlp_set_compute(1) / Model(compute_dtype="bfloat16"): BASELINE config 2's arithmetic -- GEMM operands
     rounded to bf16 at the MFMA, fp32 accumulation.  Not the parity path: the results must sit within bf16's 2^-8

@@ -28,7 +28,7 @@ def test_driver_reads_like_the_reference(cuda, tmp_path, capsys):
 
     model = get_model()
     model.compile(optimizer="adam", loss=CategoricalCrossentropy(), metrics=["accuracy"])
-    ckpt = str(tmp_path / "bin" / "models_constrained" / "TEST.pt")
+    ckpt = str(tmp_path / "bin" / "models_constrained" / "TEST.h5")
     cst = simple_norm_constraint(rho=0.1, affected_layers_indices=[])
     hist = model.fit(train_dataset, epochs=6, validation_data=val_dataset, verbose=2,
                      callbacks=[EarlyStopping(monitor="val_loss", patience=6000, restore_best_weights=False), cst, lip_stats_callback(),
