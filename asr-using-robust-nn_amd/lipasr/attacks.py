@@ -564,3 +564,43 @@ def black_box_attack_on_audio_dataset_snr(filenames, target_snr_db, seed=None):
         for (i, _), row in zip(items, f):
             out[i] = row
     return out
+
+
+def black_box_attack_on_audio(file_path, utterance_length, sigma=0, p=0, alpha=0, seed=None):
+    """attacks.py:89-121: one file -> noisy MFCC (20, utterance_length), float32 NumPy."""
+    x, sr = read_wav(file_path)
+    f = noisy_audio_to_mfcc(x[None, :], sr, sigma=sigma, p=p, alpha=alpha, seed=seed, utterance_length=utterance_length)
+    return f.view(20, utterance_length).cpu().numpy()
+
+
+def black_box_attack_on_audio_snr(file_path, utterance_length, target_snr_db, seed=None):
+    """attacks.py:248-274."""
+    x, sr = read_wav(file_path)
+    f = noisy_audio_to_mfcc(x[None, :], sr, target_snr_db=target_snr_db, seed=seed, utterance_length=utterance_length)
+    return f.view(20, utterance_length).cpu().numpy()
+
+
+def mixtgauss(N_, p, sigma0, sigma1, seed=None):
+    """attacks.py:145-163: N_ samples of the impulse mixture (sigma1 where |N(0,1)| < p, sigma0 elsewhere), drawn by the
+    device generator -- add_noise's noise term on its own."""
+    if abs(sigma1 - 10 * sigma0) > 1e-12 * max(1.0, abs(sigma1)):
+        raise NotImplementedError("mixtgauss with sigma1 != 10 sigma0 (the reference's only call, attacks.py:178-180, uses 10x)")
+    z = torch.zeros(int(N_), device=_dev())
+    h = N.get_handle(z.device.index)
+    if seed is None:
+        _noise_calls[0] += 1
+        seed = 0xA77AC000 + _noise_calls[0]
+    N.check(N.lib.lipasr_add_noise_f32(h.h, N.ptr(z), 1, z.numel(), 1, float(p), float(sigma0), int(seed), N.stream_ptr()))
+    return z.cpu().numpy()
+
+
+def load_npy_dataset(path):
+    """attacks.py:27-45: the six ``.npy`` files of a processed dataset folder (``path`` ends with a separator, as in the
+    reference's call sites)."""
+    import os
+
+    def ld(name):
+        return np.load(os.path.join(path, name) if os.path.isdir(path) else path + name)
+
+    return (ld("train_data.npy"), ld("train_label.npy"), ld("dev_data.npy"), ld("dev_label.npy"), ld("test_data.npy"),
+            ld("test_label.npy"))

@@ -186,3 +186,68 @@ def get_lipschitz_constrained(model):
     cst = float(sig.item())
     correction = float(np.prod([float(f.item()) for f in factors])) if factors else 1.0
     return cst / correction
+
+
+# ------------------------------------------------------------------------------------------------ dataset construction
+digit = ['zero', 'one', 'two', 'three', 'four', 'five', 'six', 'seven', 'eight', 'nine']  # reference :120
+
+
+def get_file_names_and_labels(file_path, classes=None):
+    """Reference :118-141: the class folders of ``file_path`` that exist (in the order of ``digit``), every file in
+    them, and one integer label per file -- the label is the folder's rank among the folders that are PRESENT."""
+    import glob
+    import os
+
+    classes = digit if classes is None else classes
+    present = set(os.listdir(str(file_path)))
+    filenames, labels = [], []
+    for i, name in enumerate([c for c in classes if c in present]):
+        found = sorted(glob.glob(os.path.join(str(file_path), name, "*")))
+        filenames += found
+        labels += [i] * len(found)
+    return filenames, np.array(labels)
+
+
+def shuffle(*arrays, random_state=None):
+    """sklearn.utils.shuffle (reference :205): one permutation applied to every argument; lists stay lists."""
+    if not arrays:
+        return None
+    n = len(arrays[0])
+    if any(len(a) != n for a in arrays):
+        raise ValueError("shuffle: arguments of different lengths")
+    rng = random_state if isinstance(random_state, np.random.RandomState) else np.random.RandomState(random_state)
+    perm = rng.permutation(n)
+    out = [[a[i] for i in perm] if isinstance(a, (list, tuple)) else np.asarray(a)[perm] for a in arrays]
+    return out[0] if len(out) == 1 else out
+
+
+def split_train_dev_test(items):
+    """Reference :208-214: [:0.7 n], [0.7 n : 0.9 n], [-0.1 n:] with the reference's int() truncations (for n < 10 the
+    last slice is ``[-0:]``, i.e. everything, exactly as the reference's expression evaluates)."""
+    n = len(items)
+    a, b, c = int(n * 0.7), int(n * 0.9), int(n * 0.1)
+    return items[:a], items[a:b], items[-c:]
+
+
+def main(data_dir="data", save_dir="processed_google_dataset", noise_dir="test_dataset_to_add_noise", random_state=None):
+    """Reference :198-232 (the ``__main__`` block): list, shuffle, split 70/20/10, MFCC of every file on the GPU,
+    and the eight ``.npy`` files train_constraints.py:16-25 and attacks.py read."""
+    import os
+
+    filenames, labels = get_file_names_and_labels(data_dir)
+    filenames, labels = shuffle(filenames, labels, random_state=random_state)
+    filenames_train, filenames_dev, filenames_test = split_train_dev_test(filenames)
+    labels_train, labels_dev, labels_test = split_train_dev_test(labels)
+    os.makedirs(noise_dir, exist_ok=True)
+    os.makedirs(save_dir, exist_ok=True)
+    np.save(os.path.join(noise_dir, "test_label"), labels_test)
+    np.save(os.path.join(noise_dir, "test_filenames"), filenames_test)
+    for name, files, lab in (("train", filenames_train, labels_train), ("dev", filenames_dev, labels_dev),
+                             ("test", filenames_test, labels_test)):
+        np.save(os.path.join(save_dir, f"{name}_data"), compute_mfcc_all_files(files))
+        np.save(os.path.join(save_dir, f"{name}_label"), lab)
+    return save_dir
+
+
+if __name__ == "__main__":
+    main()

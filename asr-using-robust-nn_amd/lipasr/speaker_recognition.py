@@ -118,6 +118,36 @@ def load_audio_dataset_and_labels(filenames, labels):
     return feats.cpu().numpy().astype(np.float64), np.array(local_labels)
 
 
+def get_file_names_and_labels(file_path):
+    """Speaker recognition/extract_features_construct_dataset.py:114-137: the speaker folders that are present."""
+    from .extract_features_construct_dataset import get_file_names_and_labels as _list
+
+    return _list(file_path, classes=digit)
+
+
+def main(data_dir="dataset/rodigits", save_dir="RoDigits_splitV2", noise_dir="test_dataset_to_add_noise", random_state=None):
+    """Speaker recognition/extract_features_construct_dataset.py:236-267: recordings are split 70/20/10 BEFORE
+    windowing, every recording becomes 1-s windows with its label repeated, and the windowed MFCCs are saved."""
+    import os
+
+    from .extract_features_construct_dataset import shuffle, split_train_dev_test
+
+    filenames, labels = get_file_names_and_labels(data_dir)
+    filenames, labels = shuffle(filenames, labels, random_state=random_state)
+    parts = list(zip(("train", "dev", "test"), split_train_dev_test(filenames), split_train_dev_test(labels)))
+    os.makedirs(noise_dir, exist_ok=True)
+    os.makedirs(save_dir, exist_ok=True)
+    out = {}
+    for name, files, lab in parts:
+        out[name] = load_audio_dataset_and_labels(files, lab)
+    np.save(os.path.join(noise_dir, "test_label"), out["test"][1])
+    np.save(os.path.join(noise_dir, "test_filenames"), parts[2][1])
+    for name in ("train", "dev", "test"):
+        np.save(os.path.join(save_dir, f"{name}_data"), out[name][0])
+        np.save(os.path.join(save_dir, f"{name}_label"), out[name][1])
+    return save_dir
+
+
 def get_model(**kw):
     """Speaker recognition/train_constraints.py:63-88 (the voice-digit network with 2020 inputs, 20 outputs)."""
     inp = Input((N_FEATURES,))

@@ -83,14 +83,29 @@ def synthetic_dataset(n_train=16566, n_dev=4733, n_test=2366, seed=1234):
     return (feats[:a], labels[:a]), (feats[a:b], labels[a:b]), (feats[b:], labels[b:])
 
 
+def load_processed_dataset(path="processed_google_dataset/"):
+    """train_constraints.py:16-25: the six ``.npy`` files extract_features_construct_dataset.main() writes."""
+    import os
+
+    def ld(name):
+        return np.load(os.path.join(path, name + ".npy"))
+
+    return (ld("train_data"), ld("train_label")), (ld("dev_data"), ld("dev_label")), (ld("test_data"), ld("test_label"))
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--epochs", type=int, default=5)
     ap.add_argument("--rho", type=float, default=0.1)
     ap.add_argument("--small", action="store_true", help="2048/512/512 clips instead of the reference's split sizes")
+    ap.add_argument("--data", default=None, help="directory with train/dev/test _data.npy and _label.npy "
+                                                 "(train_constraints.py:16-25); default: synthetic clips")
     args = ap.parse_args(argv)
     sizes = (2048, 512, 512) if args.small else (16566, 4733, 2366)
-    (train_data, train_label), (val_data, val_label), (test_data, test_label1) = synthetic_dataset(*sizes)
+    if args.data:
+        (train_data, train_label), (val_data, val_label), (test_data, test_label1) = load_processed_dataset(args.data)
+    else:
+        (train_data, train_label), (val_data, val_label), (test_data, test_label1) = synthetic_dataset(*sizes)
     train_label, val_label, test_label = (to_categorical(l, 10) for l in (train_label, val_label, test_label1))
     train_data, val_data, test_data = standardize_dataset(train_data, val_data, test_data)
 

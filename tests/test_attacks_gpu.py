@@ -142,6 +142,51 @@ def test_device_noise_statistics(cuda):
     assert np.abs(loud - clean).max() > 1.0
 
 
+def test_file_level_black_box_helpers(cuda, tmp_path):
+    """attacks.py:27-45, 89-121, 145-163, 248-274: the per-file forms of the audio attacks, the mixture generator and
+    the dataset loader -- the single-file result is the corresponding row of the batched dataset call (same seed)."""
+    import wave
+
+    from lipasr.attacks import (black_box_attack_on_audio, black_box_attack_on_audio_dataset, black_box_attack_on_audio_dataset_snr,
+                                black_box_attack_on_audio_snr, load_npy_dataset, mixtgauss)
+    from lipasr.extract_features_construct_dataset import extract_features
+
+    rng = np.random.default_rng(3)
+    files = []
+    for k in range(3):
+        x = 0.3 * np.sin(2 * np.pi * (300 + 100 * k) * np.arange(16000) / 16000.0) + 0.01 * rng.standard_normal(16000)
+        path = tmp_path / f"c{k}.wav"
+        with wave.open(str(path), "wb") as f:
+            f.setnchannels(1); f.setsampwidth(2); f.setframerate(16000)
+            f.writeframes((np.clip(x, -1, 1) * 32767.0).astype("<i2").tobytes())
+        files.append(str(path))
+    clean = black_box_attack_on_audio(files[0], 44)
+    assert clean.shape == (20, 44) and clean.dtype == np.float32
+    np.testing.assert_allclose(clean, extract_features(files[0], 44), rtol=0, atol=1e-5)  # sigma = p = alpha = 0: no noise branch
+    ds = black_box_attack_on_audio_dataset(files, 0.02, 0, 0, seed=5)
+    one = black_box_attack_on_audio(files[0], 44, sigma=0.02, seed=5)
+    np.testing.assert_allclose(one.reshape(-1), ds[0], rtol=0, atol=1e-4)
+    assert np.abs(one - clean).max() > 0.5
+    mix = black_box_attack_on_audio(files[1], 30, p=0.05, alpha=0.01, seed=6)
+    assert mix.shape == (20, 30) and np.abs(mix - extract_features(files[1], 30)).max() > 0.1
+    snr_ds = black_box_attack_on_audio_dataset_snr(files, 15.0, seed=7)
+    snr_one = black_box_attack_on_audio_snr(files[0], 44, 15.0, seed=7)
+    np.testing.assert_allclose(snr_one.reshape(-1), snr_ds[0], rtol=0, atol=1e-4)
+    g = mixtgauss(400000, 0.01, 0.002, 0.02, seed=8).astype(np.float64)
+    frac = 0.0079787  # P(|N(0,1)| < 0.01)
+    assert abs(g.var() - ((1 - frac) * 0.002 ** 2 + frac * 0.02 ** 2)) < 4e-7 and abs(g.mean()) < 2e-5
+    with pytest.raises(NotImplementedError):
+        mixtgauss(10, 0.01, 0.002, 0.5)
+    d = tmp_path / "processed"
+    d.mkdir()
+    arrays = {n: rng.standard_normal((4, 3)) for n in ("train_data", "train_label", "dev_data", "dev_label", "test_data", "test_label")}
+    for n, a in arrays.items():
+        np.save(d / n, a)
+    got = load_npy_dataset(str(d) + "/")
+    for a, n in zip(got, ("train_data", "train_label", "dev_data", "dev_label", "test_data", "test_label")):
+        np.testing.assert_array_equal(a, arrays[n])
+
+
 def test_class_gradient_and_output_vjp(cuda):
     """ART class_gradient: gradients of the softmax outputs, and the logits variant of the same VJP."""
     from lipasr.attacks import TensorFlowV2Classifier
