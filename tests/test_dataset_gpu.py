@@ -134,3 +134,53 @@ def test_speaker_dataset_construction(cuda, tmp_path):
         ref = M.sr_mfcc_windows(np.concatenate(wins))
         assert np.abs(feats - ref).max() < ATOL
     assert np.load(os.path.join(noise, "test_filenames.npy")).tolist() == list(parts_f[2])
+
+
+@pytest.mark.gpu
+def test_attack_evaluation_driver(cuda, tmp_path, capsys):
+    """attacks.py:296-693 as flags (lipasr.attack_eval): wav corpus -> .npy dataset -> two trained .h5 models ->
+    black-box sweeps over audio and over MFCC, white-box FGSM / PGD sweeps.  Strength 0 must reproduce the clean
+    accuracy, and accuracies are probabilities."""
+    from lipasr import attack_eval as V
+    from lipasr import attacks as A
+    from lipasr import extract_features_construct_dataset as E
+    from lipasr import keras as K
+    from lipasr import train_constraints as T
+
+    rng = np.random.default_rng(5)
+    data = tmp_path / "data"
+    _make_corpus(data, E.digit, 8, rng)
+    save, noise = str(tmp_path / "processed_google_dataset") + "/", str(tmp_path / "test_dataset_to_add_noise")
+    E.main(data_dir=str(data), save_dir=save, noise_dir=noise, random_state=2)
+    train_data, train_label, val_data, val_label, test_data, test_label = A.load_npy_dataset(save)
+    tr, va, _ = A.standardize_dataset(train_data, val_data, test_data)
+    paths = {}
+    for name, build in (("constrained", T.get_model), ("unconstrained", T.get_model_unconstrained)):
+        K.reset_layer_names()
+        m = build(max_batch=64)
+        m.compile(optimizer="adam", loss=K.CategoricalCrossentropy(), metrics=["accuracy"])
+        m.fit(K.Dataset.from_tensor_slices((tr, K.to_categorical(train_label, 10))).batch(56), epochs=6, verbose=0)
+        paths[name] = str(tmp_path / "bin" / f"{name}.h5")
+        m.save(paths[name])
+    base = ["--path", save, "--noise-dir", noise, "--constrained", paths["constrained"], "--unconstrained", paths["unconstrained"]]
+    models = {k: K.load_model(v, max_batch=64) for k, v in paths.items()}
+    labels = K.to_categorical(test_label, 10)
+    clean = {k: V.accuracy(m.predict(A.standardize_dataset(train_data, val_data, test_data)[2]), labels) for k, m in models.items()}
+
+    grid, acc = V.main(base + ["--attack", "black", "--kind", "simple", "--over", "mfcc", "--points", "3"])
+    assert len(grid) == 3 and grid[0] == 0 and set(acc) == {"constrained", "unconstrained"}
+    for k in acc:
+        assert acc[k][0] == clean[k] and np.all((acc[k] >= 0) & (acc[k] <= 1))
+    grid, acc = V.main(base + ["--attack", "black", "--kind", "mixture", "--over", "mfcc", "--standardize", "after", "--points", "2"])
+    assert len(grid) == 2 and acc["constrained"][0] == clean["constrained"]  # alpha = 0: no noise
+    for kind, n in (("simple", 2), ("mixture", 2), ("snr", 2)):
+        grid, acc = V.main(base + ["--attack", "black", "--kind", kind, "--over", "audio", "--points", str(n)])
+        assert len(grid) == n and all(len(v) == n for v in acc.values())
+    grid, acc = V.main(base + ["--attack", "white", "--kind", "fgsm", "--points", "2"])
+    assert np.allclose(grid, np.linspace(0.01, 0.3, 10)[:2]) and all(len(v) == 2 for v in acc.values())
+    grid, acc = V.white_box_sweep(models, train_data, val_data, test_data, labels, kind="pgd", grid=[0.5, 4.0], max_iter=5)
+    for k in acc:
+        assert acc[k][1] <= acc[k][0] <= clean[k] + 1e-12  # a stronger attack never helps the model it was made for
+    with pytest.raises(ValueError):
+        V.black_box_sweep(models, train_data, val_data, test_data, labels, kind="snr", over="mfcc")
+    assert "Accuracy on black-box attack test examples" in capsys.readouterr().out
