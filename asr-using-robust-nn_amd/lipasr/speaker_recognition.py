@@ -169,3 +169,45 @@ def get_model_unconstrained(**kw):
         hdn = Dense(units, activation="relu")(hdn)
     out = Dense(N_SPEAKERS, activation="softmax")(hdn)
     return Model(inputs=inp, outputs=out, **kw)
+
+
+def train_no_constraints_main(argv=None):
+    """Speaker recognition/train_no_constraints.py:16-43,77-97: the unconstrained baseline on RoDigits_splitV2/*.npy
+    (shuffle buffers 2000 / 1000, batch 64, EarlyStopping(patience=10)), then the per-layer norms and their product."""
+    import argparse
+
+    from .train_constraints import load_processed_dataset
+    from .train_google_dataset import run
+
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--data", default="RoDigits_splitV2/")
+    ap.add_argument("--epochs", type=int, default=10000)
+    ap.add_argument("--checkpoint", default="bin/models/baseline_splitV2.h5")
+    args = ap.parse_args(argv)
+    model, y, results = run(get_model_unconstrained(max_batch=64), load_processed_dataset(args.data), N_SPEAKERS, batch=64,
+                            epochs=args.epochs, patience=10, checkpoint=args.checkpoint, max_batch=64, shuffle=(2000, 1000))
+    lip = get_upper_lipschitz(get_norms(model))
+    print(f"Upper Lipschitz constant for non-constrained model: {lip}")
+    return model, results, lip
+
+
+def train_constraints_main(argv=None):
+    """Speaker recognition/train_constraints.py:17-42,91-113: the constrained network with
+    simple_norm_constraint(rho=1, affected_layers_indices=[]), batch 64, then the BatchNorm-corrected Lipschitz constant."""
+    import argparse
+
+    from .train_constraints import load_processed_dataset
+    from .train_google_dataset import run
+
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--data", default="RoDigits_splitV2/")
+    ap.add_argument("--epochs", type=int, default=10000)
+    ap.add_argument("--rho", type=float, default=1.0)
+    ap.add_argument("--checkpoint", default="bin/models_constrained/model_constrained_Rho1_splitV2_batch_norm.h5")
+    args = ap.parse_args(argv)
+    model, y, results = run(get_model(max_batch=64), load_processed_dataset(args.data), N_SPEAKERS, batch=64, epochs=args.epochs,
+                            patience=2000, checkpoint=args.checkpoint, max_batch=64,
+                            callbacks=[simple_norm_constraint(rho=args.rho, affected_layers_indices=[])])
+    lip = get_lipschitz_constrained(model)
+    print(f"Lipschitz constant for constrained model: {lip}")
+    return model, results, lip

@@ -184,3 +184,38 @@ def test_attack_evaluation_driver(cuda, tmp_path, capsys):
     with pytest.raises(ValueError):
         V.black_box_sweep(models, train_data, val_data, test_data, labels, kind="snr", over="mfcc")
     assert "Accuracy on black-box attack test examples" in capsys.readouterr().out
+
+
+@pytest.mark.gpu
+def test_remaining_training_drivers(cuda, tmp_path, capsys):
+    """train_google_dataset.py:76-99 (baseline + confusion matrix) and the two Speaker-recognition drivers
+    (SR/train_no_constraints.py:77-97, SR/train_constraints.py:91-113) on small .npy datasets they load themselves."""
+    from lipasr import speaker_recognition as S
+    from lipasr import train_google_dataset as G
+
+    rng = np.random.default_rng(6)
+
+    def fake_dataset(folder, n_feat, n_cls, sizes=(192, 64, 64)):
+        os.makedirs(folder, exist_ok=True)
+        centers = rng.standard_normal((n_cls, n_feat)) * 2.0
+        for name, n in zip(("train", "dev", "test"), sizes):
+            lab = rng.integers(0, n_cls, n)
+            lab[:n_cls] = np.arange(n_cls)  # every class present
+            np.save(os.path.join(folder, f"{name}_data"), centers[lab] + rng.standard_normal((n, n_feat)))
+            np.save(os.path.join(folder, f"{name}_label"), lab)
+
+    vd, sr = str(tmp_path / "processed_google_dataset"), str(tmp_path / "RoDigits_splitV2")
+    fake_dataset(vd, 880, 10)
+    fake_dataset(sr, 2020, 20)
+    cm = G.confusion_matrix([0, 1, 1, 2, 2, 2], [0, 1, 2, 2, 2, 0], 3)
+    np.testing.assert_array_equal(cm, [[1, 0, 0], [0, 1, 1], [1, 0, 2]])
+    assert cm.dtype == np.int32
+    model, results, conf = G.main(["--epochs", "12", "--data", vd, "--checkpoint", str(tmp_path / "bin" / "models" / "baselineV2.h5")])
+    assert conf.shape == (10, 10) and conf.sum() == 64 and np.trace(conf) == round(results[1] * 64)
+    assert results[1] > 0.5  # well-separated classes: the baseline learns them in a few epochs
+    m2, r2, lip2 = S.train_no_constraints_main(["--epochs", "6", "--data", sr, "--checkpoint", str(tmp_path / "bin" / "sr_base.h5")])
+    assert len(m2.layers) == 7 and np.isfinite(lip2) and lip2 > 0
+    m3, r3, lip3 = S.train_constraints_main(["--epochs", "6", "--data", sr, "--checkpoint", str(tmp_path / "bin" / "sr_con.h5")])
+    assert sum("batch" in l.name for l in m3.layers) == 5 and np.isfinite(lip3) and lip3 > 0
+    out = capsys.readouterr().out
+    assert "Upper Lipschitz constant for non-constrained model" in out and "Lipschitz constant for constrained model" in out
