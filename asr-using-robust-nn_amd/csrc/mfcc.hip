@@ -462,11 +462,12 @@ struct StftArgs {
   int stage_mask;  // profiling only: bit0 skip the FFT passes, bit1 skip the mel reduction (results are wrong)
 };
 
-constexpr int kTStride = 1060;  // per-array stride of the four weighted-power arrays (padded index k + k/32 <= 1056)
+constexpr int kTPair = 1028;    // stride of the two float2 (frame 0, frame 1) weighted-power arrays, >= 1025 bins
 
 __global__ __launch_bounds__(256) void stft_mel_kernel(StftArgs a) {
   __shared__ __attribute__((aligned(16))) float2 buf[kFftLds];  // ONE buffer: 17 kB per workgroup
   __shared__ float wmax[4];
+  __shared__ float2 rsum[2][128];  // run sums (frame 0, frame 1): [weight array][run]
   const int tid = threadIdx.x;
   // XCD-aware block -> (clip, frame pair) map (speed only): workgroups are dealt round-robin over the 8 XCDs, so
   // blocks L, L+8, L+16, ... share an L2.  Giving those to consecutive frame pairs of ONE clip lets the 75 %
@@ -488,10 +489,10 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(StftArgs a) {
   const int f0 = fp * 2, f1 = f0 + 1;
   const bool has1 = f1 < a.n_frames;
   const float* yu = a.y + (size_t)u * a.n_y;
-  // per-thread constants of the mel stage (L2-resident tables) start their trip now, not after the FFT's last barrier
-  const int mel_m = tid & 127;
-  const int mst = a.mel_start[mel_m], mln = a.mel_len[mel_m];
-  const int mst2 = (mel_m > 0) ? a.mel_start[mel_m - 1] : 0, mln2 = (mel_m > 0) ? a.mel_len[mel_m - 1] : 0;
+  // per-thread constants of the mel stage (L2-resident tables) start their trip now, not after the FFT's last barrier.
+  // Wavefront w sums weight array w&1 (lower / upper filter of each bin) over run (w>>1)*64 + lane, both frames at once.
+  const int mel_part = (tid >> 6) & 1, mel_run = ((tid >> 7) << 6) + (tid & 63);
+  const int mst = a.mel_start[mel_run], mln = a.mel_len[mel_run];
   float mwl[5], mwh[5];
 #pragma unroll
   for (int i = 0; i < 5; ++i) {
@@ -501,14 +502,28 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(StftArgs a) {
   }
   // frame f covers padded positions [512 f, 512 f + 2048) = y positions [512 f - 1024, ...)
   cpx x0[8];
+  if (has1 && f0 >= 2 && f1 * 512 + 1024 <= a.n_y) {
+    // both frames lie inside the clip (20 of the 22 pairs of a 1-s clip): no reflection, and frame 1 is frame 0 moved
+    // by 512 samples = two of this thread's 256-sample steps, so ten loads feed both (workgroup-uniform branch)
+    const float* p = yu + (f0 * 512 - 1024) + tid;
+    float sm[10];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int n = tid + 256 * e;
-    const float w = a.hann[n];
-    const int j0 = f0 * 512 + n - 1024;
-    const float s0 = yu[reflect_index(j0, a.n_y)];
-    const float s1 = has1 ? yu[reflect_index(j0 + 512, a.n_y)] : 0.0f;
-    x0[e] = {w * s0, w * s1};
+    for (int e = 0; e < 10; ++e) sm[e] = p[256 * e];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float w = a.hann[tid + 256 * e];
+      x0[e] = {w * sm[e], w * sm[e + 2]};
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int n = tid + 256 * e;
+      const float w = a.hann[n];
+      const int j0 = f0 * 512 + n - 1024;
+      const float s0 = yu[reflect_index(j0, a.n_y)];
+      const float s1 = has1 ? yu[reflect_index(j0 + 512, a.n_y)] : 0.0f;
+      x0[e] = {w * s0, w * s1};
+    }
   }
   if (a.stage_mask & 1) {
 #pragma unroll
@@ -525,8 +540,9 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(StftArgs a) {
     __syncthreads();
   }
   // Z = FFT(frame0 + i frame1).  X0[k] = (Z[k] + conj Z[N-k])/2, X1[k] = (Z[k] - conj Z[N-k])/(2i).
-  // The power of bin k is multiplied straight away by its two mel weights: T[2 sel + 0][k] = wlo[k] P_sel[k],
-  // T[2 sel + 1][k] = whi[k] P_sel[k]  (four float arrays laid over the same buffer once Z has been read).
+  // The powers of bin k (frame 0, frame 1) are multiplied straight away by the bin's two mel weights and stored as
+  // PAIRS: Tlo[k] = wlo[k] (P0[k], P1[k]), Thi[k] = whi[k] (P0[k], P1[k]) -- two float2 arrays laid over the same buffer
+  // once Z has been read, so that the mel sums below move both frames with one ds_read_b64 + one packed add.
   float2 zz[5], zc[5];
 #pragma unroll
   for (int i = 0; i < 5; ++i) {
@@ -537,7 +553,7 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(StftArgs a) {
     }
   }
   __syncthreads();
-  float* T = reinterpret_cast<float*>(buf);
+  float2* T = buf;
 #pragma unroll
   for (int i = 0; i < 5; ++i) {
     const int k = tid + 256 * i;
@@ -547,27 +563,32 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(StftArgs a) {
       const float x1r = 0.5f * (zi - wi), x1i = -0.5f * (zr - wr);
       const float p0 = x0r * x0r + x0i * x0i, p1 = x1r * x1r + x1i * x1i;
       const float wl = mwl[i], wh = mwh[i];
-      const int pk = k + (k >> 5);  // runs of neighbouring mels start ~32 bins apart at the top of the band
-      T[pk] = wl * p0;
-      T[kTStride + pk] = wh * p0;
-      T[2 * kTStride + pk] = wl * p1;
-      T[3 * kTStride + pk] = wh * p1;
+      T[k] = make_float2(wl * p0, wl * p1);
+      T[kTPair + k] = make_float2(wh * p0, wh * p1);
     }
   }
   __syncthreads();
+  // mel[m] = sum over run(m) of Tlo + sum over run(m-1) of Thi.  The kernel is VALU-issue bound, so the sums are
+  // arranged for few instructions: one lane per (weight array, run) adds BOTH frames with packed adds, four loads in
+  // flight off one address; the (frame, m) threads then pick their two run sums up from a 2 kB exchange array.
   const int sel = tid >> 7, m = tid & 127;
-  const float* T1 = T + 2 * sel * kTStride;
-  const float* T2 = T1 + kTStride;
   float s = 0.0f;
   if (!(a.stage_mask & 2)) {
-    for (int i = 0; i < mln; ++i) { const int b = mst + i; s += T1[b + (b >> 5)]; }
-    if (m > 0) {
-      float s2 = 0.0f;
-      for (int i = 0; i < mln2; ++i) { const int b = mst2 + i; s2 += T2[b + (b >> 5)]; }
-      s += s2;
+    const float2* Tp = T + mel_part * kTPair + mst;
+    float2 a0 = make_float2(0.0f, 0.0f), a1 = a0, a2 = a0, a3 = a0;
+    int i = 0;
+    for (; i + 4 <= mln; i += 4) {
+      const float2 v0 = Tp[i], v1 = Tp[i + 1], v2 = Tp[i + 2], v3 = Tp[i + 3];
+      a0.x += v0.x; a0.y += v0.y; a1.x += v1.x; a1.y += v1.y;
+      a2.x += v2.x; a2.y += v2.y; a3.x += v3.x; a3.y += v3.y;
     }
+    for (; i < mln; ++i) { const float2 v = Tp[i]; a0.x += v.x; a0.y += v.y; }
+    rsum[mel_part][mel_run] = make_float2((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y));
+    __syncthreads();
+    const float* rs = reinterpret_cast<const float*>(&rsum[0][0]);
+    s = rs[2 * m + sel] + ((m > 0) ? rs[2 * (128 + m - 1) + sel] : 0.0f);
   } else {
-    s = T1[m];
+    s = sel ? T[m].y : T[m].x;
   }
   const float dbv = 10.0f * log10f(fmaxf(1e-10f, s));  // librosa.power_to_db(ref=1, amin=1e-10)
   const int f = sel ? f1 : f0;
