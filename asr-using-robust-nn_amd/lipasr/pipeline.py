@@ -196,3 +196,26 @@ class TrainPipeline:
     def synchronize(self):
         self.mfcc_stream.synchronize()
         self.stream.synchronize()
+
+    @property
+    def mfcc_stream_kind(self):
+        """"masked" (its own hardware queue, confined to ``mfcc_cus`` CUs) or "shared" (a pool stream on every CU)."""
+        return "masked" if getattr(self, "_masked_stream", None) is not None else "shared"
+
+    def close(self):
+        """Drains both streams and gives the CU-masked stream (a hardware queue of its own) back.  A process that builds
+        several pipelines one after another should close the ones it is done with."""
+        st = getattr(self, "_masked_stream", None)
+        if st is None:
+            return
+        self.synchronize()
+        self._graphs.clear()
+        self._masked_stream = None
+        self.mfcc_stream = torch.cuda.Stream(device=self.dev)
+        N.lib.lipasr_stream_destroy(self.h.h, st)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -188,8 +188,10 @@ def run_config(args, batch, rank, world, device, steps, warmup, profile):
         extras["mfcc_ms"] = {"resample": ms3[0], "stft_mel": ms3[1], "dct": ms3[2], "calls": n.value}
     extras["mfcc_standalone_ms"] = standalone
     extras["mfcc_cus"] = getattr(pipe, "mfcc_cus", None)
+    extras["mfcc_stream"] = pipe.mfcc_stream_kind
     extras["n_cus"] = torch.cuda.get_device_properties(device).multi_processor_count
     assert np.isfinite(extras["loss"]), "training diverged"
+    pipe.close()  # the masked stream is a hardware queue: hand it back before the next configuration builds its own
     return dt, extras
 
 
@@ -281,13 +283,14 @@ def main():
                                   + (", data-parallel RCCL gradient all-reduce" if world > 1 else ", 1xMI355X"),
                       "baseline_config": 5 if args.pgd else (2 if args.pre_extracted else (4 if world > 1 else 3)), "global_batch": global_batch, "per_gpu_batch": batch,
                       "clip": "1 s @ 16 kHz fp32", "parallelism": f"dp{world}", "hip_graph": not args.no_graph},
-           "roofline": roofline,
+           "roofline": roofline, "mfcc_stream": ex.get("mfcc_stream"),
            "mlp_tflops": round(TRAIN_FLOP_PER_UTT * batch / max(1e-9, (ex["event_ms_per_step"] - stage_ms) * 1e-3) / 1e12, 3),
            "event_ms_per_step": round(ex["event_ms_per_step"], 4), "final_product_norm": ex["final_norm"], "loss": round(ex["loss"], 4)}
     if world == 1 and not args.skip_b512 and batch != 512:
         dt5, ex5 = run_config(args, 512, rank, world, device, args.steps, args.warmup, profile=True)
         out["reference_batch_512"] = {"value": round(512 * args.steps / dt5, 1), "ms_per_step": round(dt5 / args.steps * 1e3, 4),
-                                      "mfcc_ms": {k: round(v, 4) for k, v in ex5["mfcc_ms"].items() if k != "calls"}}
+                                      "mfcc_ms": {k: round(v, 4) for k, v in ex5["mfcc_ms"].items() if k != "calls"},
+                                      "mfcc_stream": ex5.get("mfcc_stream")}
     if world == 1 and not args.skip_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(512)
     else:
