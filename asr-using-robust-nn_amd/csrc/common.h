@@ -40,7 +40,6 @@ struct lipasr_ctx {
   int device = 0;
   // scratch for the spectral kernels (chain products, partial sums, scale factors)
   int rs_target_wgs = 256;  // persistent resampler: workgroups to aim for (lipasr_debug_set key 1); survives re-planning
-  int chain_head = 1;       // product chain: fused head kernel (lipasr_debug_set key 2; 0 = one launch per step)
   float* scratch = nullptr;
   size_t scratch_floats = 0;
   std::vector<hipEvent_t> timers;  // pairs: 2*id = start, 2*id+1 = stop

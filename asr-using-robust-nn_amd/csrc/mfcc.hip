@@ -1386,11 +1386,7 @@ int lipasr_add_noise_f32(lipasr_handle_t h, float* y, int batch, int n, int mode
  * resampler instead of the MFMA one).  Masks 1 and 2 give wrong results by design. */
 int lipasr_debug_set(lipasr_handle_t h, int key, int value) {
   LP_CHECK_ARG(h != nullptr, "lipasr_debug_set: null handle");
-  LP_CHECK_ARG(key >= 0 && key <= 2, "lipasr_debug_set: unknown key %d", key);
-  if (key == 2) {
-    h->chain_head = value ? 1 : 0;
-    return LIPASR_OK;
-  }
+  LP_CHECK_ARG(key == 0 || key == 1, "lipasr_debug_set: unknown key %d", key);
   if (!h->mfcc) { set_error("lipasr_debug_set: call lipasr_mfcc_plan first"); return LIPASR_ESTATE; }
   if (key == 1) {
     LP_CHECK_ARG(value >= 1 && value <= 4096, "lipasr_debug_set: resampler workgroup target %d", value);

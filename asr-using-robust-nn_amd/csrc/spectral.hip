@@ -157,128 +157,6 @@ __global__ __launch_bounds__(256) void chain_step_kernel(const float* __restrict
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// chain head: the first steps of the product chain multiply SMALL layers (128x64, 256x128 ...): as launches of their
-// own they are pure latency (5.8 us each, 8.7 us next to the MFCC stream).  Here every workgroup redoes those small
-// steps in LDS (n_red of them, ~160 row slots in all) and then takes its share of the rows of the NEXT step, whose
-// panel goes to global memory for chain_step_kernel to continue from: one launch instead of n_red + 1.
-// Per row the arithmetic is chain_step_kernel's, bit for bit: columns 4 l .. 4 l + 3 (+ 256 t) on sub-lane l, an
-// xor-butterfly over the row's lanes -- a row of n_in < 256 columns only occupies n_in / 4 lanes, so 64 / LPR rows
-// share a wavefront (chain_step_kernel leaves those lanes idle and adds their zeros).
-// ---------------------------------------------------------------------------------------------
-constexpr int kHeadMax = 2;        // redone steps at most
-constexpr int kHeadSlots = 8;      // row slots per wavefront and redone step (their weights are fetched up front)
-constexpr int kHeadThreads = 1024;
-constexpr int kHeadWaves = kHeadThreads / 64;
-struct HeadArgs {
-  const float* Wlast;  // [n0][R]: P starts as its transpose
-  int R, n0, n_red;
-  const float* W[kHeadMax + 1];  // steps in chain order; entry n_red is the shared one
-  int rows[kHeadMax + 1];
-  int cols[kHeadMax + 1];        // redone steps: <= 256 (one float4 per lane and row); shared step: <= 1024
-  float* Pout;  // [R][rows[n_red]]
-  int width;    // LDS panel stride in floats
-};
-
-__device__ __forceinline__ int head_lpr(int n_in) {  // lanes per row: power of two covering n_in / 4, at most 64
-  int lpr = 1;
-  while (lpr < 64 && lpr * 4 < n_in) lpr <<= 1;
-  return lpr;
-}
-
-// one row slot: NT float4 of the weight row already in registers (columns 4 sl + 256 t), panel in LDS
-template <int RM, int NT>
-__device__ __forceinline__ void head_slot(const float4 (&w)[NT], int i, bool live, int n_rows, int n_in, int R, int lpr,
-                                          int sl, const float* __restrict__ Ps, float* __restrict__ out) {
-  float acc[RM];
-#pragma unroll
-  for (int r = 0; r < RM; ++r) acc[r] = 0.0f;
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int j = sl * 4 + 256 * t;
-    if (live && j < n_in) {
-#pragma unroll
-      for (int r = 0; r < RM; ++r) {
-        if (r < R) {
-          const float4 p = *reinterpret_cast<const float4*>(Ps + r * n_in + j);
-          acc[r] = fmaf(w[t].x, p.x, acc[r]);
-          acc[r] = fmaf(w[t].y, p.y, acc[r]);
-          acc[r] = fmaf(w[t].z, p.z, acc[r]);
-          acc[r] = fmaf(w[t].w, p.w, acc[r]);
-        }
-      }
-    }
-  }
-  // butterfly over the row's lanes, the R sums side by side (R independent shuffles in flight per level, not R chains
-  // of six dependent ones); levels that would reach into a neighbouring row's lanes are skipped
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    if (o < lpr) {  // wave-uniform
-#pragma unroll
-      for (int r = 0; r < RM; ++r) acc[r] += __shfl_xor(acc[r], o, 64);
-    }
-  }
-  if (live && sl == 0) {
-#pragma unroll
-    for (int r = 0; r < RM; ++r)
-      if (r < R) out[(size_t)r * n_rows + i] = acc[r];
-  }
-}
-
-template <int RM>
-__global__ __launch_bounds__(kHeadThreads) void chain_head_kernel(HeadArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float hp[];  // two panels [R][width]
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int R = a.R;
-  // every weight this wavefront will touch starts its trip now: one memory latency for the whole kernel, not one per row
-  float4 wq[kHeadMax][kHeadSlots];
-#pragma unroll
-  for (int st = 0; st < kHeadMax; ++st) {
-    const int lpr = head_lpr(st < a.n_red ? a.cols[st] : 4), sl = lane & (lpr - 1), sub = lane / lpr, rpw = 64 / lpr;
-#pragma unroll
-    for (int it = 0; it < kHeadSlots; ++it) {
-      const int i = (wave + kHeadWaves * it) * rpw + sub;
-      const bool live = st < a.n_red && i < a.rows[st] && sl * 4 < a.cols[st];
-      wq[st][it] = live ? *reinterpret_cast<const float4*>(a.W[st] + (size_t)i * a.cols[st] + sl * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  }
-  const int c = a.n_red;
-  const int lprc = head_lpr(a.cols[c]), slc = lane & (lprc - 1);
-  const int ic = (blockIdx.x * kHeadWaves + wave) * (64 / lprc) + lane / lprc;
-  float4 wc[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int j = slc * 4 + 256 * t;
-    wc[t] = (ic < a.rows[c] && j < a.cols[c]) ? *reinterpret_cast<const float4*>(a.W[c] + (size_t)ic * a.cols[c] + j) : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  float* pa = hp;
-  float* pb = hp + (size_t)R * a.width;
-  for (int f = tid; f < R * a.n0; f += kHeadThreads) {
-    const int j = f / R, r = f - j * R;
-    pa[r * a.n0 + j] = a.Wlast[f];
-  }
-  __syncthreads();
-#pragma unroll
-  for (int st = 0; st < kHeadMax; ++st) {
-    if (st < a.n_red) {
-      const int n_in = a.cols[st], n_rows = a.rows[st];
-      const int lpr = head_lpr(n_in), sl = lane & (lpr - 1), sub = lane / lpr, rpw = 64 / lpr;
-#pragma unroll
-      for (int it = 0; it < kHeadSlots; ++it) {
-        const int i = (wave + kHeadWaves * it) * rpw + sub;
-        if ((wave + kHeadWaves * it) * rpw < n_rows) {  // wave-uniform
-          const float4 w1[1] = {wq[st][it]};
-          head_slot<RM, 1>(w1, i, i < n_rows, n_rows, n_in, R, lpr, sl, pa, pb);
-        }
-      }
-      __syncthreads();
-      float* t = pa; pa = pb; pb = t;
-    }
-  }
-  if ((blockIdx.x * kHeadWaves + wave) * (64 / lprc) < a.rows[c])
-    head_slot<RM, 4>(wc, ic, ic < a.rows[c], a.rows[c], a.cols[c], R, lprc, slc, pa, a.Pout);
-}
-
 struct OrderArgs {
   int n_layers;
   int n_order;
@@ -653,48 +531,7 @@ static int launch_chain(lipasr_ctx* h, const float* const* Ws, const int* rows, 
     pin = nullptr;
     p_mode = 2;
   }
-  int first_k = (m == 1) ? 0 : m - 2;
-  // chain head: the leading small steps redone per workgroup in LDS + the next step shared out, one launch
-  if (m >= 4 && R <= 12 && h->chain_head) {  // (20 accumulators + the prefetched rows do not fit 128 VGPRs)
-    HeadArgs ha;
-    ha.Wlast = Ws[m - 1];
-    ha.R = R;
-    ha.n0 = rows[m - 1];
-    int n_red = 0, width = rows[m - 1];
-    bool ok = ((reinterpret_cast<uintptr_t>(Ws[m - 1]) & 15) == 0);
-    for (int k = m - 2; k >= 1 && n_red <= kHeadMax && ok; --k) {
-      // step k: rows[k] new columns, cols[k] = current panel width
-      ok = ((cols[k] & 3) == 0) && ((reinterpret_cast<uintptr_t>(Ws[k]) & 15) == 0) && cols[k] <= 1024;
-      if (!ok) break;
-      int lpr = 1;
-      while (lpr < 64 && lpr * 4 < cols[k]) lpr <<= 1;
-      const int slots = (rows[k] * lpr + 63) / 64;
-      ha.W[n_red] = Ws[k];
-      ha.rows[n_red] = rows[k];
-      ha.cols[n_red] = cols[k];
-      width = cols[k] > width ? cols[k] : width;
-      if (slots > kHeadSlots * kHeadWaves || cols[k] > 256 || n_red == kHeadMax) {
-        // this step is the shared one: its panel leaves through global memory
-        const size_t lds = (size_t)2 * R * width * sizeof(float);
-        if (n_red >= 1 && lds <= 96 * 1024) {
-          ha.n_red = n_red;
-          ha.width = width;
-          ha.Pout = cs->P[cur];
-          const int blocks = (slots + kHeadWaves - 1) / kHeadWaves;
-          if (lds > 48 * 1024)
-            LP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_head_kernel<12>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-          hipLaunchKernelGGL(chain_head_kernel<12>, dim3(blocks), dim3(kHeadThreads), lds, st, ha);
-          LP_LAUNCH_CHECK();
-          pin = cs->P[cur];
-          p_mode = 0;
-          cur ^= 1;
-          first_k = k - 1;
-        }
-        break;
-      }
-      ++n_red;
-    }
-  }
+  const int first_k = (m == 1) ? 0 : m - 2;
   for (int k = first_k; k >= 0; --k) {
     // step k multiplies by W_k^T: rows of W_k are the new columns of P
     const int n_rows = rows[k];

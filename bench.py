@@ -123,8 +123,6 @@ def run_config(args, batch, rank, world, device, steps, warmup, profile):
     pipe = TrainPipeline(model, batch=batch, rho=0.1, constraint=args.constraint, affine=(sc.mean_, sc.scale_), pgd=pgd, dp=dp,
                          use_graph=not args.no_graph)
 
-    if os.environ.get("LIPASR_CHAIN_HEAD"):  # A/B knob: 0 = one launch per product-chain step
-        N.check(N.lib.lipasr_debug_set(pipe.h.h, 2, int(os.environ["LIPASR_CHAIN_HEAD"])))
     if os.environ.get("LIPASR_RS_WGS"):
         N.check(N.lib.lipasr_debug_set(pipe.h.h, 1, int(os.environ["LIPASR_RS_WGS"])))
     feat_pool = None

@@ -314,9 +314,7 @@ int lipasr_add_noise_f32(lipasr_handle_t h, float* y, int batch, int n, int mode
 /* Knobs.  key 0: MFCC stage mask for profiling (bit0 skip the FFT passes, bit1 skip the mel reduction -- both give
  * wrong results and exist to time the remaining stages; bit2 selects the VALU resampler instead of the MFMA one).
  * key 1: number of workgroups the persistent resampler aims for = the CUs its stream may use (default 256; a
- * pipeline that runs the MFCC on a CU-masked stream sets it to the size of the mask).  Kept in the handle.
- * key 2: product chain (lipasr_product_norm / lipasr_project_product ...): 1 (default) computes the leading small
- * steps in one fused launch, 0 one launch per step -- same results bit for bit, kept for A/B timing. */
+ * pipeline that runs the MFCC on a CU-masked stream sets it to the size of the mask).  Kept in the handle. */
 int lipasr_debug_set(lipasr_handle_t h, int key, int value);
 
 /* Profiling knob: GEMM kernel choice. 0 = automatic, 1 = split-K register kernel only, 2 = LDS-tiled kernel

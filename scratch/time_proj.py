@@ -7,7 +7,6 @@ for l in [l for l in m.layers if 'dense' in l.name]:
     w,b=l.get_weights(); l.set_weights([np.abs(w),b])
 norms=torch.zeros(7,device='cuda'); order=N.int_array(list(range(6)))
 h=N.get_handle(0)
-if len(sys.argv)>1: N.check(N.lib.lipasr_debug_set(h.h, 2, int(sys.argv[1])))
 s=torch.cuda.Stream()
 with torch.cuda.stream(s):
     def call(): N.check(N.lib.lipasr_mlp_project_product(m._plan, N.ptr(m._params), 0.1, order, 6, N.ptr(norms), N.stream_ptr()))
