@@ -195,7 +195,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
   float a0[8], b0[8], a1[8], b1[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) { a0[q] = b0[q] = a1[q] = b1[q] = 0.0f; }
-  // one chunk of loads in flight behind the MFMAs
+  // one chunk of loads in flight behind the MFMAs (two measured slower: config 2 0.384 -> 0.390 ms, config 5 +4 %)
   int c = wave;
   if (c < nch) {
     load_frag<AMODE>(g.A, g.lda, ai, c * 16 + 8 * h, g.K, vecA, a0, aones);
@@ -433,54 +433,84 @@ __device__ __forceinline__ void tile_store(float* __restrict__ S, int tid, const
   }
 }
 
-template <int AMODE, int BMODE, bool BF = false>
+constexpr int kLdsBKMax = 32;  // 64-row tiles measured slower (30.4 vs 26.3 us on the 1024x1024x880 GEMM)
+constexpr size_t lds_gemm_bytes(int bk) {
+  return ((size_t)(2 * 2 * bk * kLdsLD > 2 * 64 * 64 ? 2 * 2 * bk * kLdsLD : 2 * 64 * 64) + 8 * 16 * 8) * sizeof(float);
+}
+
+template <int AMODE, int BMODE, bool BF = false, int BK = kLdsBKMax>  // BK: k rows per LDS tile (32 or 64)
 __global__ __launch_bounds__(512) void gemm_lds_kernel(GemmArgs g) {
   constexpr int TS = 64;
-  __shared__ __attribute__((aligned(16))) float lds[2 * 2 * kLdsBK * kLdsLD];  // [buf][A|B][32][68]; reused as [2][64][64]
-  __shared__ float stat[8 * 16 * 8];
+  constexpr int NF = BK / kLdsBK;  // 32-row fetches per operand and tile
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [buf][A|B][BK][68]; reused as [2][64][64]; then stat
+  float* stat = lds + (2 * 2 * BK * kLdsLD > 2 * 64 * 64 ? 2 * 2 * BK * kLdsLD : 2 * 64 * 64);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int kh = wave >> 2, wi = (wave >> 1) & 1, wj = wave & 1;
   const int m0 = blockIdx.y * TS, n0 = blockIdx.x * TS;
   const int m_real = g.ones_row ? g.M - 1 : g.M;
-  const int nst = (g.K + kLdsBK - 1) / kLdsBK;
+  const int nst = (g.K + BK - 1) / BK;
   const bool ones = g.ones_row != 0;
   f32x16 acc;
 #pragma unroll
   for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
-  float4 ra = tile_fetch<AMODE>(g.A, g.lda, m0, m_real, 0, g.K, ones, g.M - 1, tid);
-  float4 rb = tile_fetch<BMODE>(g.B, g.ldb, n0, g.N, 0, g.K, false, 0, tid);
-  tile_store<AMODE>(lds, tid, ra);
-  tile_store<BMODE>(lds + kLdsBK * kLdsLD, tid, rb);
+  // Operand tiles travel global/L2 -> registers -> LDS.  A k-step's MFMAs take 0.25 us per 32 k rows, an L2 round trip
+  // more: with the fetch of tile t+1 issued at the top of step t and stored at its bottom, every step waited for memory
+  // (28 steps x ~0.8 us on the 880-deep layer-1 GEMMs).  The ring below keeps TWO tiles in flight (tile t+2 is
+  // requested at the top of step t and stored at the bottom of step t+1): 29.1 -> 26.3 us on that GEMM.
+  struct Tile { float4 a[NF], b[NF]; };
+  auto fetch = [&](Tile& tl, const int t) {
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      tl.a[f] = tile_fetch<AMODE>(g.A, g.lda, m0, m_real, t * BK + f * kLdsBK, g.K, ones, g.M - 1, tid);
+      tl.b[f] = tile_fetch<BMODE>(g.B, g.ldb, n0, g.N, t * BK + f * kLdsBK, g.K, false, 0, tid);
+    }
+  };
+  auto park = [&](const Tile& tl, const int t) {
+    float* An = lds + (t & 1) * 2 * BK * kLdsLD;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      tile_store<AMODE>(An + f * kLdsBK * kLdsLD, tid, tl.a[f]);
+      tile_store<BMODE>(An + BK * kLdsLD + f * kLdsBK * kLdsLD, tid, tl.b[f]);
+    }
+  };
+  Tile t0, t1;
+  fetch(t0, 0);
+  if (nst > 1) fetch(t1, 1);
+  park(t0, 0);
   __syncthreads();
-  for (int t = 0; t < nst; ++t) {
-    // fp32: lane half h takes k = h + 2 s of its 16 (one 32x32x2 per s); bf16: k = 8 h + s (one 32x32x16 for all)
+  // one k-step: request tile t+2 into the free register slot, multiply tile t out of LDS, park tile t+1 (requested one
+  // step ago) in the other LDS buffer
+  auto kstep = [&](const int t, Tile& free_slot, const Tile& ready) {
+    if (t + 2 < nst) fetch(free_slot, t + 2);
+    // this wavefront's K half of the tile: BK/2 rows from (BK/2) kh, in groups of 16.  fp32: lane half h takes
+    // k = h + 2 s of a group (one 32x32x2 per s); bf16: k = 8 h + s (one 32x32x16 per group)
     constexpr int kstr = BF ? kLdsLD : 2 * kLdsLD;
     const int koff = BF ? 8 * h : h;
-    const float* As = lds + (t & 1) * 2 * kLdsBK * kLdsLD + (16 * kh + koff) * kLdsLD + 32 * wi + r;
-    const float* Bs = lds + (t & 1) * 2 * kLdsBK * kLdsLD + kLdsBK * kLdsLD + (16 * kh + koff) * kLdsLD + 32 * wj + r;
-    if (t + 1 < nst) {
-      ra = tile_fetch<AMODE>(g.A, g.lda, m0, m_real, (t + 1) * kLdsBK, g.K, ones, g.M - 1, tid);
-      rb = tile_fetch<BMODE>(g.B, g.ldb, n0, g.N, (t + 1) * kLdsBK, g.K, false, 0, tid);
-    }
-    float av[8], bv[8];
+    const float* base = lds + (t & 1) * 2 * BK * kLdsLD + ((BK / 2) * kh + koff) * kLdsLD + r;
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      av[s] = As[s * kstr];
-      bv[s] = Bs[s * kstr];
-    }
-    if (BF) {
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(to_bf16x8(av), to_bf16x8(bv), acc, 0, 0, 0);
-    } else {
+    for (int q = 0; q < BK / 32; ++q) {
+      const float* As = base + 16 * q * kLdsLD + 32 * wi;
+      const float* Bs = base + BK * kLdsLD + 16 * q * kLdsLD + 32 * wj;
+      float av[8], bv[8];
 #pragma unroll
-      for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc, 0, 0, 0);
+      for (int s = 0; s < 8; ++s) {
+        av[s] = As[s * kstr];
+        bv[s] = Bs[s * kstr];
+      }
+      if (BF) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(to_bf16x8(av), to_bf16x8(bv), acc, 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc, 0, 0, 0);
+      }
     }
-    if (t + 1 < nst) {
-      float* An = lds + ((t + 1) & 1) * 2 * kLdsBK * kLdsLD;
-      tile_store<AMODE>(An, tid, ra);
-      tile_store<BMODE>(An + kLdsBK * kLdsLD, tid, rb);
-    }
+    if (t + 1 < nst) park(ready, t + 1);
     __syncthreads();
+  };
+  for (int t = 0; t < nst; t += 2) {
+    kstep(t, t0, t1);                    // even step: slot 0 is free (tile t is in LDS), slot 1 holds tile t+1
+    if (t + 1 < nst) kstep(t + 1, t1, t0);  // odd step: the roles swap
   }
   // accumulators -> LDS as two 64x64 partial tiles (one per K half), then the shared epilogue shape
   float* red = lds;
@@ -619,10 +649,19 @@ static int launch_gemm(int amode, int bmode, const GemmArgs& g, hipStream_t st) 
   }
   if (use_lds_gemm(g.M, g.N, g.K)) {
     const dim3 grid((g.N + 63) / 64, (g.M + 63) / 64);
+    constexpr size_t lds_b = lds_gemm_bytes(kLdsBKMax);
 #define LP_LDS(A_, B_)                                                                              \
   {                                                                                                 \
-    if (g.bf16) hipLaunchKernelGGL((gemm_lds_kernel<A_, B_, true>), grid, dim3(512), 0, st, g);     \
-    else hipLaunchKernelGGL((gemm_lds_kernel<A_, B_, false>), grid, dim3(512), 0, st, g);           \
+    static bool attr_set = false;                                                                   \
+    if (!attr_set) {                                                                                \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_lds_kernel<A_, B_, true>),       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);            \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_lds_kernel<A_, B_, false>),      \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);            \
+      attr_set = true;                                                                              \
+    }                                                                                               \
+    if (g.bf16) hipLaunchKernelGGL((gemm_lds_kernel<A_, B_, true>), grid, dim3(512), lds_b, st, g); \
+    else hipLaunchKernelGGL((gemm_lds_kernel<A_, B_, false>), grid, dim3(512), lds_b, st, g);       \
   }
     if (amode == 0 && bmode == 0) LP_LDS(0, 0) else if (amode == 0 && bmode == 1) LP_LDS(0, 1)
     else if (amode == 1 && bmode == 0) LP_LDS(1, 0) else LP_LDS(1, 1)
