@@ -19,7 +19,9 @@ NOT done: a stand-in for a library the image lacks is not a reference run.  So:
   n_k = n0^((5/6)^k) rho^(1-(5/6)^k) for ``simple_norm_constraint``) and LAPACK SVD.
 * ``mfcc_ref``   -- librosa/resampy/scipy.fftpack restated from their published algorithm
   (early-2022 defaults); checked by analytic signals (tone resampling, filter-bank shape), SciPy's
-  Hann / DCT, and ``torch.stft`` for both window shapes (2048/512 and the Speaker-recognition 441/220).
+  Hann / DCT, ``torch.stft`` for both window shapes (2048/512 and the Speaker-recognition 441/220), and
+  ``transformers.audio_utils`` (an independent re-implementation of librosa's Slaney mel bank, power spectrogram
+  and power_to_db) + ``scipy.fftpack.dct`` for the whole chain after the resampler (``mfcc_22k``).
 * ``mlp_ref``    -- TensorFlow/Keras restated; checked by finite-difference gradients, by torch autograd
   for every gradient it produces (training and inference mode, the output VJP), by scikit-learn's own
   ``StandardScaler`` and by ``torch.optim.Adam`` in the eps -> 0 limit.

@@ -407,3 +407,65 @@ def test_adam_oracle_equals_torch_adam_up_to_epsilon_placement():
         wt.grad = torch.tensor(g)
         opt.step()
     np.testing.assert_allclose(w, wt.detach().numpy(), rtol=1e-10, atol=1e-13)
+
+
+# ------------------------------------------------------------------------------------------------
+# The feature stages after the resampler against transformers.audio_utils -- an independent implementation of
+# librosa's mel filter bank (norm="slaney", mel_scale="slaney"), centred reflect-padded power spectrogram and
+# power_to_db that ships in this image (the Whisper feature extractor's code path), with scipy.fftpack for the DCT:
+# together they ARE librosa.feature.mfcc(y, sr=22050) step by step (extract_features_construct_dataset.py:31).
+# ------------------------------------------------------------------------------------------------
+def _audio_utils():
+    try:
+        from transformers import audio_utils
+    except Exception as e:  # the product does not need it; only this pin does
+        pytest.skip(f"transformers.audio_utils is not importable: {e}")
+    for name in ("mel_filter_bank", "window_function", "spectrogram", "power_to_db"):
+        if not hasattr(audio_utils, name):
+            pytest.skip(f"transformers.audio_utils has no {name}")
+    return audio_utils
+
+
+@pytest.mark.parametrize("n_fft", [2048, 441])
+def test_mel_bank_and_window_equal_transformers(n_fft):
+    AU = _audio_utils()
+    fb = AU.mel_filter_bank(num_frequency_bins=1 + n_fft // 2, num_mel_filters=128, min_frequency=0.0, max_frequency=11025.0,
+                            sampling_rate=22050, norm="slaney", mel_scale="slaney")
+    mine = M.mel_filterbank(n_fft=n_fft)
+    assert mine.shape == fb.T.shape
+    assert np.abs(fb.T - mine).max() <= 1e-8  # float32 rounding of a bank whose largest weight is 0.04
+    np.testing.assert_array_equal((fb.T != 0), (mine != 0))  # the same two-filters-per-bin sparsity the kernels rely on
+    w = AU.window_function(n_fft, "hann", periodic=True)
+    assert np.abs(w - M.hann_periodic(n_fft)).max() <= 1e-15
+
+
+def test_power_to_db_equals_transformers():
+    AU = _audio_utils()
+    rng = np.random.default_rng(0)
+    S = np.abs(rng.standard_normal((128, 44))) ** 2 * 10.0 ** rng.uniform(-14, 3, (128, 44))
+    S[3, 5] = 0.0  # below amin
+    np.testing.assert_allclose(M.power_to_db(S), AU.power_to_db(S, reference=1.0, min_value=1e-10, db_range=80.0), rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("n_fft,hop,n", [(2048, 512, 22050), (2048, 512, 9000), (441, 220, 22050)])
+def test_mfcc_after_resampling_equals_transformers_plus_scipy(n_fft, hop, n):
+    """mfcc_22k (STFT -> power -> 128 Slaney mels -> dB with top_db 80 -> DCT-II ortho, 20 coefficients) for the
+    voice-digit window (2048/512) and the Speaker-recognition one (441/220)."""
+    import scipy.fftpack
+
+    AU = _audio_utils()
+    rng = np.random.default_rng(n_fft + n)
+    t = np.arange(n) / 22050.0
+    y = (0.3 * np.sin(2 * np.pi * 440 * t * (1 + 0.3 * t)) + 0.02 * rng.standard_normal(n)).astype(np.float32)
+    fb = AU.mel_filter_bank(num_frequency_bins=1 + n_fft // 2, num_mel_filters=128, min_frequency=0.0, max_frequency=11025.0,
+                            sampling_rate=22050, norm="slaney", mel_scale="slaney")
+    db = AU.spectrogram(y.astype(np.float64), window=AU.window_function(n_fft, "hann", periodic=True), frame_length=n_fft,
+                        hop_length=hop, fft_length=n_fft, power=2.0, center=True, pad_mode="reflect", mel_filters=fb,
+                        log_mel="dB", reference=1.0, min_value=1e-10, db_range=80.0)
+    want = scipy.fftpack.dct(db, axis=0, type=2, norm="ortho")[:20]
+    got = M.mfcc_22k(y, np.float32, n_fft, hop)
+    assert got.shape == want.shape
+    # the oracle runs the reference's float32 arithmetic, the peer float64: same budget as test_oracle_rounding_budget
+    assert np.abs(got - want).max() <= 2e-3
+    got64 = M.mfcc_22k(y.astype(np.float64), np.float64, n_fft, hop)
+    assert np.abs(got64 - want).max() <= 5e-5  # float64 inside, returned as float32 (values up to ~170: ulp 1.5e-5)
