@@ -126,3 +126,26 @@ def test_projection_full_network_closed_form(cuda):
     ws2 = [l.get_weights()[0] for l in m.layers if "dense" in l.name]
     assert abs(R.sigma_max(R.product_chain(ws2)) - 0.1) <= 1e-4
     assert all((w >= 0).all() for w in ws2)
+
+
+def test_gradient_is_additive_over_shards_at_full_size(cuda):
+    """The identity the data-parallel step rests on, at config 4's shard size: with 1/global-batch
+    folded into the loss gradient, the flat gradient of 1024 rows is the SUM of the gradients of its two 512-row shards
+    (a network without BatchNorm: per-replica statistics are the documented deviation)."""
+    widths = [880, 1024, 512, 256, 128, 64, 10]
+    spec = [P.LayerSpec(a, b, False, 0.0, True) for a, b in zip(widths[:-1], widths[1:])]
+    m = build_model(spec, max_batch=B)
+    load_params(m, P.init_params(spec, seed=12, dtype=np.float32, nonneg_init=True))
+    rng = np.random.default_rng(2)
+    x = dev(rng.standard_normal((B, 880)).astype(np.float32) * 0.1)
+    y = dev(P.to_categorical(rng.integers(0, 10, B), 10))
+
+    def grad(lo, hi):
+        m.train_fwd_bwd(x[lo:hi].contiguous(), y[lo:hi].contiguous(), inv_batch=1.0 / B, dropout=False)
+        torch.cuda.synchronize()
+        return m._grads.double().cpu().numpy().copy()
+
+    full = grad(0, B)
+    parts = grad(0, 512) + grad(512, B)
+    assert np.abs(full).max() > 0
+    assert np.abs(full - parts).max() <= 2e-5 * np.abs(full).max()
