@@ -78,8 +78,16 @@ class TrainPipeline:
             # 0.506 / 0.532 / 0.528 with 240 / 224 / 208 / 192 / 176 / 160 / 144 / 128 CUs for the MFCC stream
             # (a heavier extractor wants a larger share: the 441/220 Speaker-recognition path measured 0.904 ms unmasked,
             # 0.865 / 0.826 / 0.811 with 160 / 192 / 224 CUs)
+            # re-measured at the end of round 2 (after the STFT / GEMM changes): batch 1024: 0.540 / 0.505 / 0.489 / 0.520 ms
+            # with 128 / 160 / 192 / 224 CUs; batch 512: 0.340 with 160, 0.349 with 192 -- the MFCC work grows with the
+            # batch, the classifier's kernel chain hardly does, so the larger batch wants the larger share
             env = os.environ.get("LIPASR_MFCC_CUS")
-            mfcc_cus = int(env) if env is not None else ((n_cu * 7) // 8 if self._custom_ex else (n_cu * 5) // 8)
+            if env is not None:
+                mfcc_cus = int(env)
+            elif self._custom_ex:
+                mfcc_cus = (n_cu * 7) // 8
+            else:
+                mfcc_cus = (n_cu * 3) // 4 if self.batch >= 768 else (n_cu * 5) // 8
         if not mfcc_cus or mfcc_cus >= n_cu:
             return torch.cuda.Stream(device=self.dev)
         # Measured on MI355X (scratch/cu_mask_probe.py): mask bits act in groups of 8 consecutive bits -- group g
