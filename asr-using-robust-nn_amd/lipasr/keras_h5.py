@@ -93,12 +93,14 @@ def chain_from_config(cfg):
         k, c = layer["class_name"], layer["config"]
         lname = c.get("name", layer.get("name"))
         if i == 0 and k != "InputLayer":  # Sequential without an explicit Input: the first layer carries the shape
-            shape = c.get("batch_input_shape")
+            shape = c.get("batch_input_shape") or c.get("batch_shape")
             if not shape:
                 raise ValueError("the first layer has no batch_input_shape")
             chain.append(("Input", int(shape[-1]), f"{lname}_input"))
         if k == "InputLayer":
-            shape = c["batch_input_shape"]
+            shape = c.get("batch_input_shape") or c.get("batch_shape")  # (Keras 3's legacy-h5 writer says batch_shape)
+            if not shape:
+                raise ValueError(f"InputLayer {lname} has no batch_input_shape")
             if len(shape) != 2:
                 raise NotImplementedError(f"input shape {shape} (flat feature vectors only)")
             chain.append(("Input", int(shape[1]), lname))

@@ -160,6 +160,12 @@ def test_model_config_is_what_keras_writes():
     assert ls[3]["config"]["rate"] == 0.1
     assert cfg["config"]["input_layers"] == [["input_1", 0, 0]] and cfg["config"]["output_layers"] == [["dense_2", 0, 0]]
     assert KH.chain_from_config(json.dumps(cfg)) == CHAIN
+    # Keras 3's legacy-h5 spelling of the same config: batch_shape, module / registered_name keys
+    k3 = json.loads(json.dumps(cfg))
+    k3["config"]["layers"][0]["config"]["batch_shape"] = k3["config"]["layers"][0]["config"].pop("batch_input_shape")
+    k3["config"]["layers"][1]["config"]["kernel_constraint"] = {"module": "keras.constraints", "class_name": "NonNeg", "config": {},
+                                                               "registered_name": None}
+    assert KH.chain_from_config(k3) == CHAIN
     # rejected: what the kernels do not implement
     bad = json.loads(json.dumps(cfg))
     bad["config"]["layers"][2]["config"]["epsilon"] = 1e-5
