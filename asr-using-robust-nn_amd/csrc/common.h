@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cmath>
+#include <algorithm>
 #include <vector>
 #include "../../include/lipasr.h"
 
@@ -36,6 +37,8 @@ struct MfccPlan;
 
 }  // namespace lipasr
 
+struct lipasr_mlp;
+
 struct lipasr_ctx {
   int device = 0;
   // scratch for the spectral kernels (chain products, partial sums, scale factors)
@@ -44,7 +47,10 @@ struct lipasr_ctx {
   size_t scratch_floats = 0;
   std::vector<hipEvent_t> timers;  // pairs: 2*id = start, 2*id+1 = stop
   std::vector<hipGraphExec_t> graphs;
-  lipasr::MfccPlan* mfcc = nullptr;
+  std::vector<hipStream_t> streams;        // CU-masked streams made by lipasr_stream_create_masked and still alive
+  std::vector<struct lipasr_mlp*> mlps;    // classifier plans made on this handle and still alive
+  lipasr::MfccPlan* mfcc = nullptr;               // the handle's default MFCC plan (lipasr_mfcc_plan); also in mfcc_plans
+  std::vector<lipasr::MfccPlan*> mfcc_plans;      // every MFCC plan made on this handle and still alive
 };
 
 namespace lipasr {

@@ -13,6 +13,7 @@ void set_error(const char* fmt, ...) {
 }
 
 void mfcc_plan_free(MfccPlan* p);  // mfcc.hip
+void mlp_plan_free(lipasr_mlp* m);   // dense.hip
 
 }  // namespace lipasr
 
@@ -20,7 +21,7 @@ using namespace lipasr;
 
 extern "C" {
 
-int lipasr_version(void) { return 200; }  // round 2
+int lipasr_version(void) { return 300; }  // round 3
 
 const char* lipasr_last_error(void) { return g_err; }
 
@@ -55,13 +56,31 @@ int lipasr_create(int device, lipasr_handle_t* out) {
   return LIPASR_OK;
 }
 
+// Everything the handle made is released here, in dependency order, while the HIP runtime is still up: a HIP object
+// that outlives the process's exit handlers is torn down by the runtime's own static destructors, and for a CU-masked
+// stream (a hardware queue of its own) with graph executables instantiated on it that teardown ran after the
+// profiler's queue interception had been finalised ("exit-time SIGSEGV").  Order: drain the device, graph
+// executables (they reference streams' captured nodes and plan buffers), masked streams, plans, events, scratch.
 int lipasr_destroy(lipasr_handle_t h) {
   LP_CHECK_ARG(h != nullptr, "lipasr_destroy: null handle");
   DeviceGuard g(h->device);
-  for (hipEvent_t e : h->timers) (void)hipEventDestroy(e);
+  (void)hipDeviceSynchronize();
   for (hipGraphExec_t ge : h->graphs)
     if (ge) (void)hipGraphExecDestroy(ge);
-  if (h->mfcc) mfcc_plan_free(h->mfcc);
+  h->graphs.clear();
+  for (hipStream_t st : h->streams)
+    if (st) (void)hipStreamDestroy(st);
+  h->streams.clear();
+  // plans still alive are the handle's to free (their pointers die with it)
+  std::vector<lipasr_mlp*> mlps;
+  mlps.swap(h->mlps);
+  for (lipasr_mlp* m : mlps) mlp_plan_free(m);
+  std::vector<MfccPlan*> plans;
+  plans.swap(h->mfcc_plans);
+  for (MfccPlan* p : plans) mfcc_plan_free(p);
+  h->mfcc = nullptr;
+  for (hipEvent_t e : h->timers) (void)hipEventDestroy(e);
+  h->timers.clear();
   if (h->scratch) (void)hipFree(h->scratch);
   delete h;
   return LIPASR_OK;
@@ -145,6 +164,7 @@ int lipasr_stream_create_masked(lipasr_handle_t h, const uint32_t* cu_mask, int 
   DeviceGuard g(h->device);
   hipStream_t st = nullptr;
   LP_HIP(hipExtStreamCreateWithCUMask(&st, (uint32_t)n_words, cu_mask));
+  h->streams.push_back(st);
   *out = st;
   return LIPASR_OK;
 }
@@ -152,7 +172,13 @@ int lipasr_stream_create_masked(lipasr_handle_t h, const uint32_t* cu_mask, int 
 int lipasr_stream_destroy(lipasr_handle_t h, lipasr_stream_t stream) {
   LP_CHECK_ARG(h && stream, "lipasr_stream_destroy: null argument");
   DeviceGuard g(h->device);
-  LP_HIP(hipStreamDestroy(static_cast<hipStream_t>(stream)));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  bool mine = false;
+  for (hipStream_t& s : h->streams)
+    if (s == st) { s = nullptr; mine = true; }
+  LP_CHECK_ARG(mine, "lipasr_stream_destroy: not a live stream of this handle");
+  LP_HIP(hipStreamSynchronize(st));
+  LP_HIP(hipStreamDestroy(st));
   return LIPASR_OK;
 }
 

@@ -967,6 +967,12 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
 
 static inline size_t align4(size_t x) { return (x + 3) & ~size_t(3); }
 
+void mlp_plan_free(lipasr_mlp* m) {
+  if (!m) return;
+  if (m->ws) (void)hipFree(m->ws);
+  delete m;
+}
+
 }  // namespace lipasr
 
 using namespace lipasr;
@@ -1053,6 +1059,7 @@ int lipasr_mlp_create(lipasr_handle_t h, int n_layers, const int* widths, const 
     return LIPASR_ENOMEM;
   }
   (void)hipMemset(m->ws, 0, wo * sizeof(float));
+  h->mlps.push_back(m);
   *out = m;
   return LIPASR_OK;
 }
@@ -1060,8 +1067,10 @@ int lipasr_mlp_create(lipasr_handle_t h, int n_layers, const int* widths, const 
 int lipasr_mlp_destroy(lipasr_mlp_t m) {
   LP_CHECK_ARG(m != nullptr, "lipasr_mlp_destroy: null plan");
   DeviceGuard g(m->ctx->device);
-  if (m->ws) (void)hipFree(m->ws);
-  delete m;
+  std::vector<lipasr_mlp*>& v = m->ctx->mlps;
+  for (size_t i = 0; i < v.size(); ++i)
+    if (v[i] == m) { v.erase(v.begin() + i); break; }
+  lipasr::mlp_plan_free(m);
   return LIPASR_OK;
 }
 

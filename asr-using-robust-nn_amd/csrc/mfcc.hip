@@ -22,6 +22,7 @@ namespace lipasr {
 using namespace tables;
 
 struct MfccPlan {
+  lipasr_ctx* ctx = nullptr;  // owning handle
   int sr_in = 0, n_samp = 0, batch_max = 0;
   int up = 1, down = 1, taps = 0, left = 0;
   int n_valid = 0, n_y = 0, n_frames = 0;
@@ -37,6 +38,10 @@ struct MfccPlan {
   int n_ptiles = 0;
   int stage_mask = 0;        // debug/profiling: bit0 skip FFT passes, bit1 skip mel, bit2 use the VALU resampler
   int rs_target_wgs = 256;   // persistent resampler: workgroups to aim for (one per CU; fewer leaves CUs to the other stream)
+  // fused resample -> STFT kernel (mfcc_fused_kernel): frame groups of a clip of n_samp samples, {q0, f_begin, f_end, 0}
+  int* d_groups = nullptr;
+  int n_groups = 0;
+  bool fused = false;
   float* d_hann = nullptr;
   float* d_tw = nullptr;  // float2 [2048]
   float* d_twB = nullptr; // float2 [32 r][32 k]: exp(-2 pi i r k / 1024) (pass B of the wave FFT)
@@ -62,7 +67,7 @@ struct MfccPlan {
 
 void mfcc_plan_free(MfccPlan* p) {
   if (!p) return;
-  void* ptrs[] = {p->d_dft, p->d_twB, p->d_mel_wlo, p->d_mel_whi, p->d_mel_pstart, p->d_mel_plen, p->d_hband, p->d_lo, p->d_h, p->d_noff, p->d_hann, p->d_tw, p->d_mel_start, p->d_mel_len, p->d_mel_off,
+  void* ptrs[] = {p->d_groups, p->d_dft, p->d_twB, p->d_mel_wlo, p->d_mel_whi, p->d_mel_pstart, p->d_mel_plen, p->d_hband, p->d_lo, p->d_h, p->d_noff, p->d_hann, p->d_tw, p->d_mel_start, p->d_mel_len, p->d_mel_off,
                   p->d_mel_w, p->d_dct, p->d_y, p->d_db, p->d_fmax};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
@@ -910,6 +915,330 @@ __global__ __launch_bounds__(64 * kDftMaxTiles) __attribute__((amdgpu_waves_per_
 }
 
 // ---------------------------------------------------------------------------------------------
+// stages 1 + 2 fused: the resampled signal never leaves the CU.
+//
+//   One workgroup = (clip, frame group).  A frame group is a run of STFT frames whose reflect-padded windows lie
+//   inside 16 consecutive q-blocks of the resampled clip (16 x 441 = 7056 samples; a 1-s clip has the four groups
+//   12 | 10 | 10 | 12 frames, built on the host by build_groups()).  The workgroup
+//     1. stages the input samples of its 16 q-blocks in LDS (float4 / short4 loads; int16 PCM is scaled by 2^-15 here,
+//        which is librosa.load's decode; samples outside [0, n_valid) are zero = resampy's tap-count clamps),
+//     2. resamples them with the polyphase contraction of resample_mfma_kernel on v_mfma_f32_16x16x4_f32 -- rows are
+//        the 16 q-blocks of ONE clip (A operand from LDS: row stride down + 2 floats, so the 16 rows x 2 k-columns of a
+//        half-wave hit 32 different banks), columns 2 x 16 phases sharing one A read, K = the 152-sample band -- and
+//        writes the 7056 resampled samples to a second LDS region (fix_length zeros past int(n * ratio)),
+//     3. runs the frame pairs of its group as complex 2048-point FFTs straight from that region (the code of
+//        stft_mel_kernel; the x staging area becomes the FFT buffer), with the Hann weights, all radix-8 / radix-4
+//        twiddles and the mel-stage constants of each thread loaded ONCE per workgroup instead of once per frame pair.
+//   HBM traffic of the stage drops from 4.5x to about 1.4x the algorithmic bytes (the resampled signal's 88 kB per clip
+//   written and 89 kB read back are gone; the 16-q windows of neighbouring groups overlap by ~30 %, served from L2).
+//   The MFMA pipe (resampling) and the VALU (FFT butterflies) belong to different phases of a workgroup; with three
+//   workgroups per CU in different phases the two pipes overlap.
+//   Clips of different lengths in one launch: n_valid[u] samples of clip u are real, the rest of its row is ignored;
+//   lengths, frame count and the reflect padding follow the clip's own length (the group table is the one of the
+//   longest clip: frames a shorter clip does not have are skipped).
+// ---------------------------------------------------------------------------------------------
+constexpr int kFuQ = 16;                                    // q-blocks per workgroup = rows of the 16x16x4 MFMA
+constexpr int kFuUp = 441;
+constexpr int kFuYLds = kFuQ * kFuUp + 8;                   // resampled span (floats)
+constexpr int kFuXMax = kFuQ * 320 + 160;                   // staged input samples at down = 320 (last row's band end)
+constexpr int kFuXLds = kFuXMax + 2 * (kFuXMax / 160) + 6;  // + 2 pad floats per q-block (down >= 160)
+constexpr int kFuULds = (kFuXLds > 2 * kFftLds ? kFuXLds : 2 * kFftLds);  // union: x staging | FFT buffer
+constexpr int kFuLdsFloats = kFuYLds + kFuULds + 2 * 2 * 128 + 8;
+typedef float fu_f32x4 __attribute__((ext_vector_type(4)));
+
+struct FusedArgs {
+  const void* wav;     // [batch][row_stride] float32 or int16
+  long row_stride;     // samples between clips
+  int n_samp_max;      // samples per row that may be valid
+  const int* n_valid;  // [batch] or null (= n_samp_max everywhere)
+  int sr_in, down;
+  int vec;             // rows are 16-byte (f32) / 8-byte (i16) aligned: vector loads
+  const float* Hband;  // [n_ptiles][kRsBand][32]
+  const int* lo;       // [n_ptiles]
+  int n_ptiles;
+  const int4* groups;
+  int n_groups;
+  StftArgs st;         // n_y / n_frames of the LONGEST clip: strides of db / fmax
+};
+
+// per-clip lengths, the expressions of tables::resampled_lengths (librosa.load -> resampy int(n ratio), fix_length ceil)
+__device__ __forceinline__ void clip_lengths(int n, int sr_in, int* n_vy, int* n_y, int* n_frames) {
+  const double r = (double)kSr / (double)sr_in;
+  const double v = (double)n * r;
+  *n_vy = (int)v;
+  *n_y = (int)ceil(v);
+  *n_frames = (*n_y >= 2) ? 1 + *n_y / kHop : 0;
+}
+
+// one Stockham pass with the butterfly's twiddles already in registers (w[r-1] = w^r)
+template <int R>
+__device__ __forceinline__ void fft_pass_regs(float2* __restrict__ buf, int Ns, int j, const cpx (&w)[R - 1], const cpx* __restrict__ regs) {
+  constexpr int NR = 2048 / R;
+  cpx v[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (regs) {
+      v[r] = regs[r];
+    } else {
+      const float2 t = buf[padi(j + r * NR)];
+      v[r] = {t.x, t.y};
+    }
+  }
+  if (!regs) __syncthreads();
+  if (Ns > 1) {
+#pragma unroll
+    for (int r = 1; r < R; ++r) v[r] = cmul(v[r], w[r - 1]);
+  }
+  butterfly(v);
+  const int k = j & (Ns - 1);
+  const int j0 = (j - k) * R + k;
+#pragma unroll
+  for (int r = 0; r < R; ++r) buf[padi(j0 + r * Ns)] = make_float2(v[r].re, v[r].im);
+}
+
+template <int R>
+__device__ __forceinline__ void load_tw(const float2* __restrict__ tw, int j, int Ns, cpx (&w)[R - 1]) {
+  const int tstep = (j & (Ns - 1)) * (2048 / (Ns * R));
+#pragma unroll
+  for (int r = 1; r < R; ++r) {
+    const float2 t = tw[(r * tstep) & 2047];
+    w[r - 1] = {t.x, t.y};
+  }
+}
+
+template <bool I16>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void mfcc_fused_kernel(FusedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float fl[];
+  float* ys = fl;                     // resampled span
+  float* xs = fl + kFuYLds;           // input staging, later the FFT buffer
+  float2* buf = reinterpret_cast<float2*>(xs);
+  float2* rsum = reinterpret_cast<float2*>(fl + kFuYLds + kFuULds);  // [2][128]
+  float* wmax = fl + kFuYLds + kFuULds + 2 * 2 * 128;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // XCD-aware block -> (clip, group) map (speed only): the groups of one clip go to one XCD, whose L2 then serves
+  // the ~30 % of input samples neighbouring groups share
+  int u, g;
+  {
+    const int ng = gridDim.x, L = blockIdx.y * gridDim.x + blockIdx.x, nb = gridDim.y;
+    const int full = (nb / 8) * 8 * ng;
+    if (L < full) {
+      const int chunk = L >> 3;
+      u = (chunk / ng) * 8 + (L & 7);
+      g = chunk % ng;
+    } else {
+      u = blockIdx.y;
+      g = blockIdx.x;
+    }
+  }
+  int n = a.n_samp_max;
+  if (a.n_valid) n = min(max(a.n_valid[u], 0), a.n_samp_max);
+  int n_vy, n_y, n_frames;
+  clip_lengths(n, a.sr_in, &n_vy, &n_y, &n_frames);
+  const int4 G = a.groups[g];
+  const int q0 = G.x, fb = G.y, fe = min(G.z, n_frames);
+  if (fb >= fe) return;  // this clip has no frame in the group (workgroup-uniform)
+  const int down = a.down;
+  // ---- 1. stage the input: element i of the staging area = sample xbase + i, stored at i + 2 (i / down)
+  {
+    const int xbase = down * q0 - 64;
+    const int x_count = kFuQ * down + 160;
+    const size_t row = (size_t)u * a.row_stride;
+    for (int v = tid; v < x_count / 4; v += 256) {
+      const int i4 = 4 * v, sidx = xbase + i4;
+      float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f;
+      if (a.vec && sidx >= 0 && sidx + 3 < n) {
+        if (I16) {
+          const short4 t = *reinterpret_cast<const short4*>(static_cast<const short*>(a.wav) + row + sidx);
+          e0 = (float)t.x * (1.0f / 32768.0f); e1 = (float)t.y * (1.0f / 32768.0f);
+          e2 = (float)t.z * (1.0f / 32768.0f); e3 = (float)t.w * (1.0f / 32768.0f);
+        } else {
+          const float4 t = *reinterpret_cast<const float4*>(static_cast<const float*>(a.wav) + row + sidx);
+          e0 = t.x; e1 = t.y; e2 = t.z; e3 = t.w;
+        }
+      } else if (sidx + 3 >= 0 && sidx < n) {
+        float e[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int sc = sidx + c;
+          e[c] = 0.f;
+          if (sc >= 0 && sc < n)
+            e[c] = I16 ? (float)static_cast<const short*>(a.wav)[row + sc] * (1.0f / 32768.0f) : static_cast<const float*>(a.wav)[row + sc];
+        }
+        e0 = e[0]; e1 = e[1]; e2 = e[2]; e3 = e[3];
+      }
+      float* d = xs + i4 + 2 * (i4 / down);  // 8-byte aligned: two ds_write_b64
+      *reinterpret_cast<float2*>(d) = make_float2(e0, e1);
+      *reinterpret_cast<float2*>(d + 2) = make_float2(e2, e3);
+    }
+  }
+  __syncthreads();
+  // ---- 2. polyphase resampling on the matrix cores: Y[q-block i][phase] = X_i[band] . Hband
+  {
+    const int ir = lane & 15, kk = lane >> 4;
+    const float* xrow = xs + (down + 2) * ir;
+    for (int r = wave; r < a.n_ptiles; r += 4) {
+      const int lo_r = a.lo[r];
+      const float* hb = a.Hband + (size_t)r * kRsBand * 32 + kk * 32 + ir;
+      float b0[kRsBand / 4], b1[kRsBand / 4];
+#pragma unroll
+      for (int s2 = 0; s2 < kRsBand / 4; ++s2) {
+        b0[s2] = hb[s2 * 128];
+        b1[s2] = hb[s2 * 128 + 16];
+      }
+      const int t0 = lo_r + 1 + kk;
+      const float* pa = xrow + t0;
+      const int cross = down - t0;  // band position t0 + 4 s lies in the next q-block's 320 samples once 4 s >= cross
+      fu_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s2 = 0; s2 < kRsBand / 4; ++s2) {
+        const float av = pa[4 * s2 + ((4 * s2 >= cross) ? 2 : 0)];
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0[s2], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1[s2], acc1, 0, 0, 0);
+      }
+      // C layout: column (phase) = lane & 15, row (q-block) = 4 (lane >> 4) + e
+#pragma unroll
+      for (int jh = 0; jh < 2; ++jh) {
+        const int ph = 32 * r + 16 * jh + ir;
+        if (ph < kFuUp) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int rw = 4 * kk + e;
+            const int t = kFuUp * (q0 + rw) + ph;
+            const float val = jh ? acc1[e] : acc0[e];
+            ys[kFuUp * rw + ph] = (t < n_vy) ? val : 0.0f;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- 3. the frame pairs of the group, from LDS
+  const StftArgs& st = a.st;
+  const int ybase = kFuUp * q0;
+  // per-thread constants, once per workgroup: Hann weights, twiddles of passes 2-4, mel weights and runs
+  float hw[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) hw[e] = st.hann[tid + 256 * e];
+  cpx w2[7], w3[7], w4a[3], w4b[3];
+  load_tw<8>(st.tw, tid, 8, w2);
+  load_tw<8>(st.tw, tid, 64, w3);
+  load_tw<4>(st.tw, tid, 512, w4a);
+  load_tw<4>(st.tw, tid + 256, 512, w4b);
+  const int mel_part = (tid >> 6) & 1, mel_run = ((tid >> 7) << 6) + (tid & 63);
+  const int mst = st.mel_start[mel_run], mln = st.mel_len[mel_run];
+  float mwl[5], mwh[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int k = tid + 256 * i;
+    mwl[i] = (k <= 1024) ? st.mel_wlo[k] : 0.0f;
+    mwh[i] = (k <= 1024) ? st.mel_whi[k] : 0.0f;
+  }
+  for (int f0 = fb; f0 < fe; f0 += 2) {
+    const int f1 = f0 + 1;
+    const bool has1 = f1 < fe;  // fe <= n_frames; a pair never straddles two groups (groups hold whole pairs)
+    // The thread index is made opaque inside the loop: every LDS address of the five passes depends on it alone, and
+    // hoisted out of the loop as invariants those ~90 addresses would push the per-thread tables into scratch.
+    int tq = tid;
+    asm volatile("" : "+v"(tq));
+    cpx x0[8];
+    if (has1 && f0 >= 2 && f1 * 512 + 1024 <= n_y) {
+      const float* p = ys + (f0 * 512 - 1024 - ybase) + tq;
+      float sm[10];
+#pragma unroll
+      for (int e = 0; e < 10; ++e) sm[e] = p[256 * e];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x0[e] = {hw[e] * sm[e], hw[e] * sm[e + 2]};
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int j0 = f0 * 512 + tq + 256 * e - 1024;
+        const float s0 = ys[reflect_index(j0, n_y) - ybase];
+        const float s1 = has1 ? ys[reflect_index(j0 + 512, n_y) - ybase] : 0.0f;
+        x0[e] = {hw[e] * s0, hw[e] * s1};
+      }
+    }
+    {
+      const cpx none7[7] = {};
+      fft_pass_regs<8>(buf, 1, tq, none7, x0);
+      __syncthreads();
+      fft_pass_regs<8>(buf, 8, tq, w2, nullptr);
+      __syncthreads();
+      fft_pass_regs<8>(buf, 64, tq, w3, nullptr);
+      __syncthreads();
+      // radix 4, two butterflies per thread: both read, the workgroup meets, both write
+      cpx va[4], vb[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float2 ta = buf[padi(tq + r * 512)], tb = buf[padi(tq + 256 + r * 512)];
+        va[r] = {ta.x, ta.y};
+        vb[r] = {tb.x, tb.y};
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 1; r < 4; ++r) { va[r] = cmul(va[r], w4a[r - 1]); vb[r] = cmul(vb[r], w4b[r - 1]); }
+      dft4(va);
+      dft4(vb);
+      // Ns = 512: k = j, output index j + r 512
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        buf[padi(tq + r * 512)] = make_float2(va[r].re, va[r].im);
+        buf[padi(tq + 256 + r * 512)] = make_float2(vb[r].re, vb[r].im);
+      }
+      __syncthreads();
+    }
+    float2 zz[5], zc[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int k = tq + 256 * i;
+      if (k <= 1024) {
+        zz[i] = buf[padi(k)];
+        zc[i] = buf[padi((2048 - k) & 2047)];
+      }
+    }
+    __syncthreads();
+    float2* T = buf;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int k = tq + 256 * i;
+      if (k <= 1024) {
+        const float zr = zz[i].x, zi = zz[i].y, wr = zc[i].x, wi = -zc[i].y;
+        const float x0r = 0.5f * (zr + wr), x0i = 0.5f * (zi + wi);
+        const float x1r = 0.5f * (zi - wi), x1i = -0.5f * (zr - wr);
+        const float p0 = x0r * x0r + x0i * x0i, p1 = x1r * x1r + x1i * x1i;
+        T[k] = make_float2(mwl[i] * p0, mwl[i] * p1);
+        T[kTPair + k] = make_float2(mwh[i] * p0, mwh[i] * p1);
+      }
+    }
+    __syncthreads();
+    const int sel = tq >> 7, m = tq & 127;
+    {
+      const float2* Tp = T + mel_part * kTPair + mst;
+      float2 a0 = make_float2(0.0f, 0.0f), a1 = a0, a2 = a0, a3 = a0;
+      int i = 0;
+      for (; i + 4 <= mln; i += 4) {
+        const float2 v0 = Tp[i], v1 = Tp[i + 1], v2 = Tp[i + 2], v3 = Tp[i + 3];
+        a0.x += v0.x; a0.y += v0.y; a1.x += v1.x; a1.y += v1.y;
+        a2.x += v2.x; a2.y += v2.y; a3.x += v3.x; a3.y += v3.y;
+      }
+      for (; i < mln; ++i) { const float2 v = Tp[i]; a0.x += v.x; a0.y += v.y; }
+      rsum[mel_part * 128 + mel_run] = make_float2((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y));
+    }
+    __syncthreads();
+    const float* rs = reinterpret_cast<const float*>(rsum);
+    const float sacc = rs[2 * m + sel] + ((m > 0) ? rs[2 * (128 + m - 1) + sel] : 0.0f);
+    const float dbv = 10.0f * log10f(fmaxf(1e-10f, sacc));  // librosa.power_to_db(ref=1, amin=1e-10)
+    const int f = sel ? f1 : f0;
+    if (f < fe) st.db[((size_t)u * st.n_frames + f) * 128 + m] = dbv;
+    const float wm = wave_max(dbv);
+    if (lane == 0) wmax[tq >> 6] = wm;
+    __syncthreads();
+    if (tq == 0) st.fmax[(size_t)u * st.n_frames + f0] = fmaxf(wmax[0], wmax[1]);
+    if (tq == 128 && has1) st.fmax[(size_t)u * st.n_frames + f1] = fmaxf(wmax[2], wmax[3]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // stage 3: top_db floor, DCT, layout
 // ---------------------------------------------------------------------------------------------
 constexpr int kDctFrames = 64;  // frames per workgroup (blockIdx.y = chunk): LDS stays 33 kB whatever the clip length
@@ -920,30 +1249,40 @@ constexpr int kDctFrames = 64;  // frames per workgroup (blockIdx.y = chunk): LD
 // scalar loop would run): the DCT rows are the A operand (64 registers per lane, loaded from the L2-resident table
 // while the dB tile is on its way), the clamped dB tile is staged transposed in LDS (row stride 65: unit-stride,
 // conflict-free B-operand reads).  28 -> 10 us per 1024 clips against the one-output-per-thread LDS loop.
+// n_frames = frames per clip the db / frame_max arrays are laid out for; with n_valid (clips of different lengths in
+// one launch) clip u has its own, smaller count and frames past it are zero columns, as fix_frames pads them
+// (extract_features_construct_dataset.py:33-37).
 __global__ __launch_bounds__(128) void dct_kernel(const float* __restrict__ db, const float* __restrict__ frame_max,
                                                    int n_frames, int L, const float* __restrict__ dct,
                                                    const double* __restrict__ aff_mean,
-                                                   const double* __restrict__ aff_scale, float* __restrict__ out) {
+                                                   const double* __restrict__ aff_scale, float* __restrict__ out,
+                                                   const int* __restrict__ n_valid, int n_samp_max, int sr_in) {
   __shared__ float dbs[128 * (kDctFrames + 1)];  // [m][t]
   __shared__ float red[2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, u = blockIdx.x;
   const int li = lane & 31, h = lane >> 5;
   const int t0 = blockIdx.y * kDctFrames;             // first output frame of this chunk
   const int tl = min(kDctFrames, L - t0);             // output frames of this chunk (incl. zero padding)
-  const int tu = max(0, min(n_frames - t0, tl));      // of which computed from the spectrogram
+  int nf = n_frames;                                  // frames this clip really has
+  if (n_valid) {
+    int nvy, ny;
+    clip_lengths(min(max(n_valid[u], 0), n_samp_max), sr_in, &nvy, &ny, &nf);
+    nf = min(nf, n_frames);
+  }
+  const int tu = max(0, min(nf - t0, tl));            // of which computed from the spectrogram
   constexpr int tp = kDctFrames + 1;
   // dB tile: 64 frames x 128 mels = 64 floats per thread, ALL in flight at once (a plain loop keeps one load in
   // flight per thread, and every load here is a cold-L2 round trip: that was 28 of the old kernel's 30 us)
   const float* src = db + ((size_t)u * n_frames + t0) * 128;
-  const int n_valid = tu * 128;
+  const int n_live = tu * 128;
   float stage[64];
 #pragma unroll
   for (int j = 0; j < 64; ++j) {
     const int i = tid + 128 * j;
-    stage[j] = (i < n_valid) ? src[i] : 0.0f;
+    stage[j] = (i < n_live) ? src[i] : 0.0f;
   }
   float mx = -INFINITY;
-  for (int t = tid; t < n_frames; t += 128) mx = fmaxf(mx, frame_max[(size_t)u * n_frames + t]);  // whole clip
+  for (int t = tid; t < nf; t += 128) mx = fmaxf(mx, frame_max[(size_t)u * n_frames + t]);  // whole clip
   mx = wave_max(mx);
   if (lane == 0) red[wave] = mx;
   __syncthreads();
@@ -951,7 +1290,7 @@ __global__ __launch_bounds__(128) void dct_kernel(const float* __restrict__ db, 
 #pragma unroll
   for (int j = 0; j < 64; ++j) {
     const int i = tid + 128 * j;  // frame j, mel tid: consecutive lanes, consecutive banks
-    dbs[tid * tp + j] = (i < n_valid) ? fmaxf(stage[j], thr) : 0.0f;
+    dbs[tid * tp + j] = (i < n_live) ? fmaxf(stage[j], thr) : 0.0f;
   }
   __syncthreads();
   // A operand (L2-resident 10 kB table): lane (li, h) holds D[li][2 s + h], s < 64 (rows >= 20 are zero)
@@ -1052,6 +1391,35 @@ static bool build_band_tables(const Polyphase& pp, std::vector<float>* hb_out, s
   return true;
 }
 
+// Frame groups of a clip with n_y resampled samples and n_frames frames for mfcc_fused_kernel: runs of whole frame
+// pairs whose reflect-padded windows (plus one sample of slack below: a SHORTER clip in the same launch reflects around
+// its own end and may touch one sample before the window) lie inside kFuQ q-blocks starting at q0.
+static std::vector<int> build_groups(int n_y, int n_frames, int up) {
+  std::vector<int> g;
+  int f = 0;
+  while (f < n_frames) {
+    const int lo = std::max(0, kHop * f - kNFft / 2 - 1);
+    const int q0 = lo / up;
+    int fe = f;
+    while (fe < n_frames) {
+      const int cand = std::min(fe + 2, n_frames);
+      const int hi = std::min(n_y, kHop * (cand - 1) + kNFft / 2);  // one past the last sample the frames need
+      if ((hi + up - 1) / up - q0 > kFuQ) break;
+      fe = cand;
+    }
+    if (fe == f) return std::vector<int>();  // a single pair does not fit: never with 2048/512 and up = 441
+    g.push_back(q0); g.push_back(f); g.push_back(fe); g.push_back(0);
+    f = fe;
+  }
+  return g;
+}
+
+static int lo_max(const MfccPlan*, const Polyphase& pp) {
+  int m = 0;
+  for (int r = 0; 32 * r < pp.up; ++r) m = std::max(m, pp.n_off[32 * r]);
+  return m;
+}
+
 template <typename T>
 static int upload(T** dptr, const std::vector<T>& v) {
   LP_HIP(hipMalloc(dptr, v.size() * sizeof(T)));
@@ -1108,6 +1476,45 @@ static int launch_resample(const MfccPlan* p, const float* wav, int batch, float
   return LIPASR_OK;
 }
 
+static int launch_dct(const MfccPlan* p, int batch, int L, const double* am, const double* as, float* out, const int* n_valid,
+                      hipStream_t st) {
+  hipLaunchKernelGGL(dct_kernel, dim3(batch, (L + kDctFrames - 1) / kDctFrames), dim3(128), 0, st, p->d_db, p->d_fmax,
+                     p->n_frames, L, p->d_dct, am, as, out, n_valid, p->n_samp, p->sr_in);
+  LP_LAUNCH_CHECK();
+  return LIPASR_OK;
+}
+
+static void fill_stft_args(const MfccPlan* p, const float* y, StftArgs* a) {
+  a->y = y; a->n_y = p->n_y; a->n_frames = p->n_frames; a->hann = p->d_hann;
+  a->tw = reinterpret_cast<const float2*>(p->d_tw);
+  a->mel_wlo = p->d_mel_wlo; a->mel_whi = p->d_mel_whi; a->mel_start = p->d_mel_pstart; a->mel_len = p->d_mel_plen;
+  a->db = p->d_db; a->fmax = p->d_fmax;
+  a->stage_mask = p->stage_mask;
+}
+
+// stages 1 + 2 in one kernel (mfcc_fused_kernel); wav: float32 (fmt 0) or int16 PCM (fmt 1)
+static int launch_fused(const MfccPlan* p, const void* wav, int fmt, const int* n_valid, int batch, hipStream_t st) {
+  FusedArgs a;
+  a.wav = wav; a.row_stride = p->n_samp; a.n_samp_max = p->n_samp; a.n_valid = n_valid;
+  a.sr_in = p->sr_in; a.down = p->down;
+  const uintptr_t addr = reinterpret_cast<uintptr_t>(wav);
+  a.vec = fmt ? ((addr & 7) == 0 && (p->n_samp & 3) == 0) : ((addr & 15) == 0 && (p->n_samp & 3) == 0);
+  a.Hband = p->d_hband; a.lo = p->d_lo; a.n_ptiles = p->n_ptiles;
+  a.groups = reinterpret_cast<const int4*>(p->d_groups); a.n_groups = p->n_groups;
+  fill_stft_args(p, nullptr, &a.st);
+  const size_t lds = (size_t)kFuLdsFloats * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    LP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mfcc_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    LP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mfcc_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  if (fmt) hipLaunchKernelGGL(mfcc_fused_kernel<true>, dim3(p->n_groups, batch), dim3(256), lds, st, a);
+  else hipLaunchKernelGGL(mfcc_fused_kernel<false>, dim3(p->n_groups, batch), dim3(256), lds, st, a);
+  LP_LAUNCH_CHECK();
+  return LIPASR_OK;
+}
+
 static int launch_from_22k(const MfccPlan* p, const float* y, int batch, int L, const double* am, const double* as,
                            float* out, hipStream_t st, hipEvent_t mid = nullptr) {  // mid: recorded between stft_mel and dct
   StftArgs a;
@@ -1144,24 +1551,28 @@ static int launch_from_22k(const MfccPlan* p, const float* y, int batch, int L, 
   }
   LP_LAUNCH_CHECK();
   if (mid) LP_HIP(hipEventRecord(mid, st));
-  hipLaunchKernelGGL(dct_kernel, dim3(batch, (L + kDctFrames - 1) / kDctFrames), dim3(128), 0, st, p->d_db, p->d_fmax,
-                     p->n_frames, L, p->d_dct, am, as, out);
-  LP_LAUNCH_CHECK();
-  return LIPASR_OK;
+  return launch_dct(p, batch, L, am, as, out, nullptr, st);
 }
 
 }  // namespace lipasr
 
 using namespace lipasr;
 
-extern "C" {
+// opaque plan type of the C ABI
+struct lipasr_mfcc : lipasr::MfccPlan {};
 
-int lipasr_mfcc_plan(lipasr_handle_t h, int sr_in, int n_samp, int batch_max) {
-  return lipasr_mfcc_plan_ex(h, sr_in, n_samp, batch_max, kNFft, kHop);
+namespace lipasr {
+
+static void plan_unregister(MfccPlan* p) {
+  if (!p || !p->ctx) return;
+  std::vector<MfccPlan*>& v = p->ctx->mfcc_plans;
+  for (size_t i = 0; i < v.size(); ++i)
+    if (v[i] == p) { v.erase(v.begin() + i); break; }
+  if (p->ctx->mfcc == p) p->ctx->mfcc = nullptr;
 }
 
-int lipasr_mfcc_plan_ex(lipasr_handle_t h, int sr_in, int n_samp, int batch_max, int n_fft, int hop) {
-  LP_CHECK_ARG(h != nullptr, "lipasr_mfcc_plan: null handle");
+static int plan_build(lipasr_handle_t h, int sr_in, int n_samp, int batch_max, int n_fft, int hop, MfccPlan** out) {
+  LP_CHECK_ARG(h != nullptr && out != nullptr, "lipasr_mfcc_plan: null argument");
   const bool dft = !(n_fft == kNFft && hop == kHop);
   if (dft && !(n_fft >= 32 && n_fft <= 32 * kDftMaxTiles * 2 - 2 && hop >= 1 && hop <= n_fft)) {
     set_error("lipasr_mfcc_plan_ex: n_fft=%d hop=%d; supported: 2048/512 (FFT path) or 32 <= n_fft <= %d with "
@@ -1171,8 +1582,8 @@ int lipasr_mfcc_plan_ex(lipasr_handle_t h, int sr_in, int n_samp, int batch_max,
   LP_CHECK_ARG(sr_in >= 1000 && sr_in <= 384000, "lipasr_mfcc_plan: sr_in=%d outside [1000, 384000]", sr_in);
   LP_CHECK_ARG(n_samp >= 2 && batch_max >= 1, "lipasr_mfcc_plan: n_samp=%d batch_max=%d", n_samp, batch_max);
   DeviceGuard g(h->device);
-  if (h->mfcc) { mfcc_plan_free(h->mfcc); h->mfcc = nullptr; }
-  MfccPlan* p = new MfccPlan();
+  MfccPlan* p = new lipasr_mfcc();
+  p->ctx = h;
   p->sr_in = sr_in; p->n_samp = n_samp; p->batch_max = batch_max;
   p->identity = (sr_in == kSr);
   resampled_lengths(n_samp, sr_in, kSr, &p->n_valid, &p->n_y);
@@ -1205,6 +1616,16 @@ int lipasr_mfcc_plan_ex(lipasr_handle_t h, int sr_in, int n_samp, int batch_max,
           mfcc_plan_free(p);
           return rc;
         }
+      }
+    }
+    // the fused resample -> STFT kernel: 2048/512 frames, 441 phases (16 kHz and 8 kHz input), rows 2 banks apart
+    if (!dft && p->d_hband && pp.up == kFuUp && pp.left == 64 && (pp.down % 32) == 0 && pp.down >= 160 && pp.down <= 320 &&
+        (kFuQ - 1) * pp.down + lo_max(p, pp) + 1 + kRsBand <= kFuQ * pp.down + 160) {
+      std::vector<int> groups = build_groups(p->n_y, p->n_frames, pp.up);
+      if (!groups.empty()) {
+        p->n_groups = (int)groups.size() / 4;
+        if ((rc = upload(&p->d_groups, groups)) != LIPASR_OK) { mfcc_plan_free(p); return rc; }
+        p->fused = true;
       }
     }
   }
@@ -1252,92 +1673,89 @@ int lipasr_mfcc_plan_ex(lipasr_handle_t h, int sr_in, int n_samp, int batch_max,
     set_error("lipasr_mfcc_plan: intermediate allocation failed");
     return LIPASR_ENOMEM;
   }
-  h->mfcc = p;
+  h->mfcc_plans.push_back(p);
+  *out = p;
   return LIPASR_OK;
 }
 
-int lipasr_mfcc_dims(lipasr_handle_t h, int* n_y, int* n_frames) {
-  LP_CHECK_ARG(h && n_y && n_frames, "lipasr_mfcc_dims: null argument");
-  if (!h->mfcc) { set_error("lipasr_mfcc_dims: call lipasr_mfcc_plan first"); return LIPASR_ESTATE; }
-  *n_y = h->mfcc->n_y;
-  *n_frames = h->mfcc->n_frames;
-  return LIPASR_OK;
-}
-
-static int mfcc_check(const char* fn, lipasr_handle_t h, int batch, int L) {
-  LP_CHECK_ARG(h != nullptr, "%s: null handle", fn);
-  if (!h->mfcc) { set_error("%s: call lipasr_mfcc_plan first", fn); return LIPASR_ESTATE; }
-  LP_CHECK_ARG(batch >= 1 && batch <= h->mfcc->batch_max, "%s: batch %d outside [1, %d]", fn, batch, h->mfcc->batch_max);
+static int plan_check(const char* fn, const MfccPlan* p, int batch, int L) {
+  LP_CHECK_ARG(p != nullptr, "%s: null plan", fn);
+  LP_CHECK_ARG(batch >= 1 && batch <= p->batch_max, "%s: batch %d outside [1, %d]", fn, batch, p->batch_max);
   LP_CHECK_ARG(L >= 1, "%s: utterance_length=%d", fn, L);
   return LIPASR_OK;
 }
 
-int lipasr_resample_f32(lipasr_handle_t h, const float* wav, int batch, float* y, lipasr_stream_t stream) {
-  int rc = mfcc_check("lipasr_resample_f32", h, batch, 1);
-  if (rc != LIPASR_OK) return rc;
-  LP_CHECK_ARG(wav && y, "lipasr_resample_f32: null argument");
-  MfccPlan* p = h->mfcc;
+static int plan_resample(MfccPlan* p, const float* wav, int batch, float* y, hipStream_t st) {
   hipEvent_t* ev = (p->prof_n < p->prof_cap) ? &p->prof_events[5 * (size_t)p->prof_n] : nullptr;
-  if (ev) LP_HIP(hipEventRecord(ev[0], S(stream)));
-  rc = launch_resample(p, wav, batch, y, S(stream));
+  if (ev) LP_HIP(hipEventRecord(ev[0], st));
+  int rc = launch_resample(p, wav, batch, y, st);
   if (rc != LIPASR_OK) return rc;
   if (ev) {
-    LP_HIP(hipEventRecord(ev[1], S(stream)));
+    LP_HIP(hipEventRecord(ev[1], st));
     p->prof_half = true;
   }
   return LIPASR_OK;
 }
 
-int lipasr_mfcc_from_22k(lipasr_handle_t h, const float* y, int batch, int n_y, int utterance_length,
-                         const double* affine_mean, const double* affine_scale, float* out, lipasr_stream_t stream) {
-  int rc = mfcc_check("lipasr_mfcc_from_22k", h, batch, utterance_length);
-  if (rc != LIPASR_OK) return rc;
-  LP_CHECK_ARG(y && out, "lipasr_mfcc_from_22k: null argument");
-  LP_CHECK_ARG(n_y == h->mfcc->n_y, "lipasr_mfcc_from_22k: n_y=%d but the plan was made for %d", n_y, h->mfcc->n_y);
-  LP_CHECK_ARG((affine_mean == nullptr) == (affine_scale == nullptr), "lipasr_mfcc_from_22k: give both affine arrays or neither");
-  MfccPlan* p = h->mfcc;
+static int plan_from_22k(MfccPlan* p, const float* y, int batch, int n_y, int L, const double* am, const double* as, float* out,
+                         hipStream_t st) {
+  LP_CHECK_ARG(n_y == p->n_y, "lipasr_mfcc_from_22k: n_y=%d but the plan was made for %d", n_y, p->n_y);
+  LP_CHECK_ARG((am == nullptr) == (as == nullptr), "lipasr_mfcc_from_22k: give both affine arrays or neither");
   // timed only as the second half of a split extraction (a resample timing is already in the slot)
   hipEvent_t* ev = (p->prof_half && p->prof_n < p->prof_cap) ? &p->prof_events[5 * (size_t)p->prof_n] : nullptr;
-  if (ev) LP_HIP(hipEventRecord(ev[2], S(stream)));
-  rc = launch_from_22k(p, y, batch, utterance_length, affine_mean, affine_scale, out, S(stream), ev ? ev[3] : nullptr);
+  if (ev) LP_HIP(hipEventRecord(ev[2], st));
+  int rc = launch_from_22k(p, y, batch, L, am, as, out, st, ev ? ev[3] : nullptr);
   if (rc != LIPASR_OK) return rc;
   if (ev) {
-    LP_HIP(hipEventRecord(ev[4], S(stream)));
+    LP_HIP(hipEventRecord(ev[4], st));
     p->prof_half = false;
     p->prof_n++;
   }
   return LIPASR_OK;
 }
 
-int lipasr_mfcc_f32(lipasr_handle_t h, const float* wav, int batch, int utterance_length, const double* affine_mean,
-                    const double* affine_scale, float* out, lipasr_stream_t stream) {
-  int rc = mfcc_check("lipasr_mfcc_f32", h, batch, utterance_length);
-  if (rc != LIPASR_OK) return rc;
-  LP_CHECK_ARG(wav && out, "lipasr_mfcc_f32: null argument");
-  LP_CHECK_ARG((affine_mean == nullptr) == (affine_scale == nullptr), "lipasr_mfcc_f32: give both affine arrays or neither");
-  MfccPlan* p = h->mfcc;
-  hipEvent_t* ev = (!p->prof_half && p->prof_n < p->prof_cap) ? &p->prof_events[5 * (size_t)p->prof_n] : nullptr;
-  if (ev) LP_HIP(hipEventRecord(ev[0], S(stream)));
-  rc = launch_resample(p, wav, batch, p->d_y, S(stream));
-  if (rc != LIPASR_OK) return rc;
-  if (ev) {
-    LP_HIP(hipEventRecord(ev[1], S(stream)));
-    LP_HIP(hipEventRecord(ev[2], S(stream)));
+// the whole extraction.  fmt 0: float32 samples, 1: int16 PCM.  n_valid: per-clip sample counts (device) or null.
+static int plan_run(MfccPlan* p, const void* wav, int fmt, const int* n_valid, int batch, int L, const double* am, const double* as,
+                    float* out, hipStream_t st) {
+  LP_CHECK_ARG(wav && out, "lipasr_mfcc: null argument");
+  LP_CHECK_ARG(fmt == 0 || fmt == 1, "lipasr_mfcc: sample format %d (0 = float32, 1 = int16 PCM)", fmt);
+  LP_CHECK_ARG((am == nullptr) == (as == nullptr), "lipasr_mfcc: give both affine arrays or neither");
+  const bool fused = p->fused && !(p->stage_mask & 128);
+  if (!fused && (fmt != 0 || n_valid)) {
+    set_error("lipasr_mfcc: int16 input and per-clip lengths need the fused 2048/512 path (16 kHz or 8 kHz input); this plan is %d Hz, n_fft %d",
+              p->sr_in, p->n_fft);
+    return LIPASR_EUNSUPPORTED;
   }
-  rc = launch_from_22k(p, p->d_y, batch, utterance_length, affine_mean, affine_scale, out, S(stream), ev ? ev[3] : nullptr);
-  if (rc != LIPASR_OK) return rc;
+  hipEvent_t* ev = (!p->prof_half && p->prof_n < p->prof_cap) ? &p->prof_events[5 * (size_t)p->prof_n] : nullptr;
+  int rc;
+  if (fused) {
+    if (ev) {  // no separate resampling kernel: its slot stays empty, the fused kernel is timed as stft_mel
+      LP_HIP(hipEventRecord(ev[0], st));
+      LP_HIP(hipEventRecord(ev[1], st));
+      LP_HIP(hipEventRecord(ev[2], st));
+    }
+    if ((rc = launch_fused(p, wav, fmt, n_valid, batch, st)) != LIPASR_OK) return rc;
+    if (ev) LP_HIP(hipEventRecord(ev[3], st));
+    if ((rc = launch_dct(p, batch, L, am, as, out, n_valid, st)) != LIPASR_OK) return rc;
+  } else {
+    if (ev) LP_HIP(hipEventRecord(ev[0], st));
+    if ((rc = launch_resample(p, static_cast<const float*>(wav), batch, p->d_y, st)) != LIPASR_OK) return rc;
+    if (ev) {
+      LP_HIP(hipEventRecord(ev[1], st));
+      LP_HIP(hipEventRecord(ev[2], st));
+    }
+    if ((rc = launch_from_22k(p, p->d_y, batch, L, am, as, out, st, ev ? ev[3] : nullptr)) != LIPASR_OK) return rc;
+  }
   if (ev) {
-    LP_HIP(hipEventRecord(ev[4], S(stream)));
+    LP_HIP(hipEventRecord(ev[4], st));
     p->prof_n++;
   }
   return LIPASR_OK;
 }
 
-int lipasr_mfcc_profile_begin(lipasr_handle_t h, int max_calls) {
-  LP_CHECK_ARG(h != nullptr && max_calls >= 1 && max_calls <= 100000, "lipasr_mfcc_profile_begin: bad argument");
-  if (!h->mfcc) { set_error("lipasr_mfcc_profile_begin: call lipasr_mfcc_plan first"); return LIPASR_ESTATE; }
-  DeviceGuard g(h->device);
-  MfccPlan* p = h->mfcc;
+static int plan_profile_begin(MfccPlan* p, int max_calls) {
+  LP_CHECK_ARG(p != nullptr && max_calls >= 1 && max_calls <= 100000, "lipasr_mfcc_profile_begin: bad argument");
+  DeviceGuard g(p->ctx->device);
   while ((int)p->prof_events.size() < 5 * max_calls) {
     hipEvent_t e;
     LP_HIP(hipEventCreate(&e));
@@ -1349,10 +1767,8 @@ int lipasr_mfcc_profile_begin(lipasr_handle_t h, int max_calls) {
   return LIPASR_OK;
 }
 
-int lipasr_mfcc_profile_end(lipasr_handle_t h, float* avg_ms3, int* n_calls) {
-  LP_CHECK_ARG(h && avg_ms3 && n_calls, "lipasr_mfcc_profile_end: null argument");
-  if (!h->mfcc) { set_error("lipasr_mfcc_profile_end: call lipasr_mfcc_plan first"); return LIPASR_ESTATE; }
-  MfccPlan* p = h->mfcc;
+static int plan_profile_end(MfccPlan* p, float* avg_ms3, int* n_calls) {
+  LP_CHECK_ARG(p && avg_ms3 && n_calls, "lipasr_mfcc_profile_end: null argument");
   double acc[3] = {0, 0, 0};
   static const int kFrom[3] = {0, 2, 3}, kTo[3] = {1, 3, 4};
   for (int i = 0; i < p->prof_n; ++i) {
@@ -1372,6 +1788,151 @@ int lipasr_mfcc_profile_end(lipasr_handle_t h, float* avg_ms3, int* n_calls) {
   return LIPASR_OK;
 }
 
+static int plan_set(MfccPlan* p, int key, int value) {
+  LP_CHECK_ARG(p != nullptr, "lipasr_mfcc_set: null plan");
+  LP_CHECK_ARG(key == 0 || key == 1, "lipasr_mfcc_set: unknown key %d", key);
+  if (key == 1) {
+    LP_CHECK_ARG(value >= 1 && value <= 4096, "lipasr_mfcc_set: resampler workgroup target %d", value);
+    p->rs_target_wgs = value;
+    return LIPASR_OK;
+  }
+  p->stage_mask = value;
+  return LIPASR_OK;
+}
+
+}  // namespace lipasr
+
+extern "C" {
+
+// ---------------------------------------------------------------- plan objects
+int lipasr_mfcc_create(lipasr_handle_t h, int sr_in, int n_samp_max, int batch_max, int n_fft, int hop, lipasr_mfcc_t* out) {
+  LP_CHECK_ARG(out != nullptr, "lipasr_mfcc_create: out is null");
+  MfccPlan* p = nullptr;
+  int rc = plan_build(h, sr_in, n_samp_max, batch_max, n_fft, hop, &p);
+  if (rc != LIPASR_OK) return rc;
+  *out = static_cast<lipasr_mfcc*>(p);
+  return LIPASR_OK;
+}
+
+int lipasr_mfcc_destroy(lipasr_mfcc_t p) {
+  LP_CHECK_ARG(p != nullptr, "lipasr_mfcc_destroy: null plan");
+  DeviceGuard g(p->ctx->device);
+  plan_unregister(p);
+  mfcc_plan_free(p);
+  return LIPASR_OK;
+}
+
+int lipasr_mfcc_plan_dims(lipasr_mfcc_t p, int* n_y, int* n_frames, int* fused) {
+  LP_CHECK_ARG(p && n_y && n_frames, "lipasr_mfcc_plan_dims: null argument");
+  *n_y = p->n_y;
+  *n_frames = p->n_frames;
+  if (fused) *fused = p->fused ? 1 : 0;
+  return LIPASR_OK;
+}
+
+int lipasr_mfcc_extract(lipasr_mfcc_t p, const void* wav, int sample_format, const int* n_valid, int batch, int utterance_length,
+                        const double* affine_mean, const double* affine_scale, float* out, lipasr_stream_t stream) {
+  int rc = plan_check("lipasr_mfcc_extract", p, batch, utterance_length);
+  if (rc != LIPASR_OK) return rc;
+  return plan_run(p, wav, sample_format, n_valid, batch, utterance_length, affine_mean, affine_scale, out, S(stream));
+}
+
+int lipasr_mfcc_plan_resample(lipasr_mfcc_t p, const float* wav, int batch, float* y, lipasr_stream_t stream) {
+  int rc = plan_check("lipasr_mfcc_plan_resample", p, batch, 1);
+  if (rc != LIPASR_OK) return rc;
+  LP_CHECK_ARG(wav && y, "lipasr_mfcc_plan_resample: null argument");
+  return plan_resample(p, wav, batch, y, S(stream));
+}
+
+int lipasr_mfcc_plan_from_22k(lipasr_mfcc_t p, const float* y, int batch, int n_y, int utterance_length, const double* affine_mean,
+                              const double* affine_scale, float* out, lipasr_stream_t stream) {
+  int rc = plan_check("lipasr_mfcc_plan_from_22k", p, batch, utterance_length);
+  if (rc != LIPASR_OK) return rc;
+  LP_CHECK_ARG(y && out, "lipasr_mfcc_plan_from_22k: null argument");
+  return plan_from_22k(p, y, batch, n_y, utterance_length, affine_mean, affine_scale, out, S(stream));
+}
+
+int lipasr_mfcc_plan_profile_begin(lipasr_mfcc_t p, int max_calls) { return plan_profile_begin(p, max_calls); }
+int lipasr_mfcc_plan_profile_end(lipasr_mfcc_t p, float* avg_ms3, int* n_calls) { return plan_profile_end(p, avg_ms3, n_calls); }
+int lipasr_mfcc_plan_set(lipasr_mfcc_t p, int key, int value) { return plan_set(p, key, value); }
+
+// ---------------------------------------------------------------- the handle's default plan (round-1/2 entry points)
+int lipasr_mfcc_plan(lipasr_handle_t h, int sr_in, int n_samp, int batch_max) {
+  return lipasr_mfcc_plan_ex(h, sr_in, n_samp, batch_max, kNFft, kHop);
+}
+
+int lipasr_mfcc_plan_ex(lipasr_handle_t h, int sr_in, int n_samp, int batch_max, int n_fft, int hop) {
+  LP_CHECK_ARG(h != nullptr, "lipasr_mfcc_plan: null handle");
+  MfccPlan* p = nullptr;
+  int rc = plan_build(h, sr_in, n_samp, batch_max, n_fft, hop, &p);
+  if (rc != LIPASR_OK) return rc;
+  if (h->mfcc) {
+    DeviceGuard g(h->device);
+    MfccPlan* old = h->mfcc;
+    plan_unregister(old);
+    mfcc_plan_free(old);
+  }
+  h->mfcc = p;
+  return LIPASR_OK;
+}
+
+int lipasr_mfcc_dims(lipasr_handle_t h, int* n_y, int* n_frames) {
+  LP_CHECK_ARG(h && n_y && n_frames, "lipasr_mfcc_dims: null argument");
+  if (!h->mfcc) { set_error("lipasr_mfcc_dims: call lipasr_mfcc_plan first"); return LIPASR_ESTATE; }
+  *n_y = h->mfcc->n_y;
+  *n_frames = h->mfcc->n_frames;
+  return LIPASR_OK;
+}
+
+static int mfcc_check(const char* fn, lipasr_handle_t h, int batch, int L) {
+  LP_CHECK_ARG(h != nullptr, "%s: null handle", fn);
+  if (!h->mfcc) { set_error("%s: call lipasr_mfcc_plan first", fn); return LIPASR_ESTATE; }
+  return plan_check(fn, h->mfcc, batch, L);
+}
+
+int lipasr_resample_f32(lipasr_handle_t h, const float* wav, int batch, float* y, lipasr_stream_t stream) {
+  int rc = mfcc_check("lipasr_resample_f32", h, batch, 1);
+  if (rc != LIPASR_OK) return rc;
+  LP_CHECK_ARG(wav && y, "lipasr_resample_f32: null argument");
+  return plan_resample(h->mfcc, wav, batch, y, S(stream));
+}
+
+int lipasr_mfcc_from_22k(lipasr_handle_t h, const float* y, int batch, int n_y, int utterance_length,
+                         const double* affine_mean, const double* affine_scale, float* out, lipasr_stream_t stream) {
+  int rc = mfcc_check("lipasr_mfcc_from_22k", h, batch, utterance_length);
+  if (rc != LIPASR_OK) return rc;
+  LP_CHECK_ARG(y && out, "lipasr_mfcc_from_22k: null argument");
+  return plan_from_22k(h->mfcc, y, batch, n_y, utterance_length, affine_mean, affine_scale, out, S(stream));
+}
+
+int lipasr_mfcc_f32(lipasr_handle_t h, const float* wav, int batch, int utterance_length, const double* affine_mean,
+                    const double* affine_scale, float* out, lipasr_stream_t stream) {
+  int rc = mfcc_check("lipasr_mfcc_f32", h, batch, utterance_length);
+  if (rc != LIPASR_OK) return rc;
+  LP_CHECK_ARG(wav && out, "lipasr_mfcc_f32: null argument");
+  LP_CHECK_ARG((affine_mean == nullptr) == (affine_scale == nullptr), "lipasr_mfcc_f32: give both affine arrays or neither");
+  return plan_run(h->mfcc, wav, 0, nullptr, batch, utterance_length, affine_mean, affine_scale, out, S(stream));
+}
+
+int lipasr_mfcc_i16(lipasr_handle_t h, const int16_t* pcm, const int* n_valid, int batch, int utterance_length,
+                    const double* affine_mean, const double* affine_scale, float* out, lipasr_stream_t stream) {
+  int rc = mfcc_check("lipasr_mfcc_i16", h, batch, utterance_length);
+  if (rc != LIPASR_OK) return rc;
+  return plan_run(h->mfcc, pcm, 1, n_valid, batch, utterance_length, affine_mean, affine_scale, out, S(stream));
+}
+
+int lipasr_mfcc_profile_begin(lipasr_handle_t h, int max_calls) {
+  LP_CHECK_ARG(h != nullptr, "lipasr_mfcc_profile_begin: bad argument");
+  if (!h->mfcc) { set_error("lipasr_mfcc_profile_begin: call lipasr_mfcc_plan first"); return LIPASR_ESTATE; }
+  return plan_profile_begin(h->mfcc, max_calls);
+}
+
+int lipasr_mfcc_profile_end(lipasr_handle_t h, float* avg_ms3, int* n_calls) {
+  LP_CHECK_ARG(h && avg_ms3 && n_calls, "lipasr_mfcc_profile_end: null argument");
+  if (!h->mfcc) { set_error("lipasr_mfcc_profile_end: call lipasr_mfcc_plan first"); return LIPASR_ESTATE; }
+  return plan_profile_end(h->mfcc, avg_ms3, n_calls);
+}
+
 int lipasr_add_noise_f32(lipasr_handle_t h, float* y, int batch, int n, int mode, float p0, float p1, uint64_t seed,
                          lipasr_stream_t stream) {
   LP_CHECK_ARG(h && y, "lipasr_add_noise_f32: null argument");
@@ -1382,20 +1943,17 @@ int lipasr_add_noise_f32(lipasr_handle_t h, float* y, int batch, int n, int mode
   return LIPASR_OK;
 }
 
-/* Profiling knob: key 0 = MFCC stage mask (bit0 skip FFT passes, bit1 skip mel reduction, bit2 use the VALU
- * resampler instead of the MFMA one).  Masks 1 and 2 give wrong results by design. */
+/* Knobs of the handle's default plan (lipasr_mfcc_plan_set is the per-plan form).  key 0: stage mask for profiling and
+ * A/B runs (bit0 skip the FFT passes, bit1 skip the mel reduction -- wrong results by design; bit2 VALU resampler; bit7 =
+ * 128: the three-kernel path instead of the fused resample -> STFT kernel).  key 1: workgroups the persistent resampler of
+ * the three-kernel path aims for. */
 int lipasr_debug_set(lipasr_handle_t h, int key, int value) {
   LP_CHECK_ARG(h != nullptr, "lipasr_debug_set: null handle");
   LP_CHECK_ARG(key == 0 || key == 1, "lipasr_debug_set: unknown key %d", key);
   if (!h->mfcc) { set_error("lipasr_debug_set: call lipasr_mfcc_plan first"); return LIPASR_ESTATE; }
-  if (key == 1) {
-    LP_CHECK_ARG(value >= 1 && value <= 4096, "lipasr_debug_set: resampler workgroup target %d", value);
-    h->rs_target_wgs = value;  // kept in the handle: a later lipasr_mfcc_plan inherits it
-    h->mfcc->rs_target_wgs = value;
-    return LIPASR_OK;
-  }
-  h->mfcc->stage_mask = value;
-  return LIPASR_OK;
+  int rc = plan_set(h->mfcc, key, value);
+  if (rc == LIPASR_OK && key == 1) h->rs_target_wgs = value;  // kept in the handle: a later lipasr_mfcc_plan inherits it
+  return rc;
 }
 
 /* Host-only: copies one constant table (as the kernels see it) into `out`; returns the element count

@@ -94,6 +94,16 @@ PROTOTYPES = {
     "lipasr_mfcc_f32": (i32, [c_h, c_f, i32, i32, c_f, c_f, c_f, c_s]),
     "lipasr_resample_f32": (i32, [c_h, c_f, i32, c_f, c_s]),
     "lipasr_mfcc_from_22k": (i32, [c_h, c_f, i32, i32, i32, c_f, c_f, c_f, c_s]),
+    "lipasr_mfcc_i16": (i32, [c_h, c_f, c_f, i32, i32, c_f, c_f, c_f, c_s]),
+    "lipasr_mfcc_create": (i32, [c_h, i32, i32, i32, i32, i32, C.POINTER(c_h)]),
+    "lipasr_mfcc_destroy": (i32, [c_h]),
+    "lipasr_mfcc_plan_dims": (i32, [c_h, PI, PI, PI]),
+    "lipasr_mfcc_extract": (i32, [c_h, c_f, i32, c_f, i32, i32, c_f, c_f, c_f, c_s]),
+    "lipasr_mfcc_plan_resample": (i32, [c_h, c_f, i32, c_f, c_s]),
+    "lipasr_mfcc_plan_from_22k": (i32, [c_h, c_f, i32, i32, i32, c_f, c_f, c_f, c_s]),
+    "lipasr_mfcc_plan_profile_begin": (i32, [c_h, i32]),
+    "lipasr_mfcc_plan_profile_end": (i32, [c_h, C.POINTER(f32), PI]),
+    "lipasr_mfcc_plan_set": (i32, [c_h, i32, i32]),
     "lipasr_mfcc_profile_begin": (i32, [c_h, i32]),
     "lipasr_mfcc_profile_end": (i32, [c_h, C.POINTER(f32), PI]),
     "lipasr_add_noise_f32": (i32, [c_h, c_f, i32, i32, i32, f32, f32, u64, c_s]),
@@ -155,6 +165,20 @@ def stream_ptr():
 
 
 _handles = {}
+# Objects that own native resources (pipelines: graphs + masked streams; models: classifier plans; extractors: MFCC
+# plans).  shutdown() closes them newest-first and then destroys the handles, so that no HIP object of ours is left
+# for the runtime's static destructors ("exit-time SIGSEGV").  Weak references: the registry never keeps
+# an object alive.
+_owners = []
+
+
+def register_owner(obj):
+    """obj.close() must be idempotent and must not raise once the handle is gone."""
+    import weakref
+
+    _owners.append(weakref.ref(obj))
+    if len(_owners) > 256:
+        _owners[:] = [r for r in _owners if r() is not None]
 
 
 class Handle:
@@ -165,6 +189,10 @@ class Handle:
         h = c_h()
         check(lib.lipasr_create(device, C.byref(h)))
         self.h = h
+
+    @property
+    def alive(self):
+        return bool(self.h)
 
     def close(self):
         if self.h:
@@ -179,9 +207,35 @@ def get_handle(device=None) -> Handle:
         raise RuntimeError("lipasr needs an MI355X (gfx950) GPU: torch.cuda.is_available() is False and there is no CPU path")
     if device is None:
         device = torch.cuda.current_device()
-    if device not in _handles:
-        _handles[device] = Handle(device)
-    return _handles[device]
+    h = _handles.get(device)
+    if h is None or not h.alive:
+        h = _handles[device] = Handle(device)
+    return h
+
+
+def shutdown():
+    """Deterministic teardown: pipelines / models / extractors (newest first), then the handles -- graphs, CU-masked
+    streams, plans, events, scratch -- all while the HIP runtime is still up.  Registered with atexit AFTER torch was
+    imported, so it runs BEFORE torch's and the runtime's own exit handlers; safe to call more than once."""
+    owners, _owners[:] = list(_owners), []
+    for ref in reversed(owners):
+        obj = ref()
+        if obj is not None:
+            try:
+                obj.close()
+            except Exception:
+                pass
+    for h in list(_handles.values()):
+        try:
+            h.close()
+        except Exception:
+            pass
+    _handles.clear()
+
+
+import atexit  # noqa: E402
+
+atexit.register(shutdown)
 
 
 def debug_table(which: int, sr_in: int = 16000):

@@ -24,47 +24,80 @@ N_MFCC = 20
 
 
 class MfccExtractor:
-    """Plan + launch wrapper of lipasr_mfcc_plan / lipasr_mfcc_f32 for one (sr_in, n_samp, batch_max)."""
+    """One native MFCC plan (lipasr_mfcc_create: tables + intermediates of its own) for clips of up to ``n_samp`` samples
+    at ``sr_in`` Hz, ``batch_max`` clips per launch.  Extractors do not share state: a pipeline's and a validation
+    pass's extractor, or two streams, coexist on one handle.  ``n_fft`` / ``hop`` other than 2048 / 512 select the
+    short-window path (Speaker recognition)."""
 
-    def __init__(self, sr_in=16000, n_samp=16000, batch_max=512, device=None):
+    def __init__(self, sr_in=16000, n_samp=16000, batch_max=512, device=None, n_fft=2048, hop=512):
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.h = N.get_handle(self.device.index)
         self.sr_in, self.n_samp, self.batch_max = int(sr_in), int(n_samp), int(batch_max)
-        self._plan()
+        plan = N.c_h()
+        N.check(N.lib.lipasr_mfcc_create(self.h.h, self.sr_in, self.n_samp, self.batch_max, int(n_fft), int(hop), C.byref(plan)))
+        self._plan = plan
+        N.register_owner(self)
+        ny, nf, fu = C.c_int(), C.c_int(), C.c_int()
+        N.check(N.lib.lipasr_mfcc_plan_dims(plan, C.byref(ny), C.byref(nf), C.byref(fu)))
+        self.n_y, self.n_frames, self.fused = ny.value, nf.value, bool(fu.value)
 
-    def _plan(self):
-        N.check(N.lib.lipasr_mfcc_plan(self.h.h, self.sr_in, self.n_samp, self.batch_max))
-        self.h.mfcc_owner = self
-        ny, nf = C.c_int(), C.c_int()
-        N.check(N.lib.lipasr_mfcc_dims(self.h.h, C.byref(ny), C.byref(nf)))
-        self.n_y, self.n_frames = ny.value, nf.value
+    def close(self):
+        plan, self._plan = getattr(self, "_plan", None), None
+        if plan and self.h.alive:
+            N.lib.lipasr_mfcc_destroy(plan)
 
-    def _own(self):
-        # one MFCC plan lives in the handle; re-plan if another extractor replaced it
-        if getattr(self.h, "mfcc_owner", None) is not self:
-            self._plan()
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
-    def __call__(self, waves, utterance_length=STANDARD_UTTERANCE_LENGTH, mean=None, scale=None, out=None):
-        """waves: float32 device tensor [B, n_samp] -> [B, 20*utterance_length] (coefficient-major)."""
-        self._own()
+    def set(self, key, value):
+        """lipasr_mfcc_plan_set: key 0 = stage mask (128 = three-kernel path), key 1 = resampler workgroups."""
+        N.check(N.lib.lipasr_mfcc_plan_set(self._plan, int(key), int(value)))
+
+    def profile_begin(self, max_calls):
+        N.check(N.lib.lipasr_mfcc_plan_profile_begin(self._plan, int(max_calls)))
+
+    def profile_end(self):
+        """-> ({'resample', 'stft_mel', 'dct'} mean milliseconds, number of extractions timed)"""
+        ms3, n = (C.c_float * 3)(), C.c_int()
+        N.check(N.lib.lipasr_mfcc_plan_profile_end(self._plan, ms3, C.byref(n)))
+        return {"resample": ms3[0], "stft_mel": ms3[1], "dct": ms3[2]}, n.value
+
+    def __call__(self, waves, utterance_length=STANDARD_UTTERANCE_LENGTH, mean=None, scale=None, out=None, n_valid=None):
+        """waves: device tensor [B, n_samp], float32 in [-1, 1) or int16 PCM -> [B, 20*utterance_length] (coefficient-major).
+        n_valid: int32 device tensor [B]: samples of each row that belong to the clip (clips of different lengths in one
+        launch; the rest of a row is ignored)."""
+        if self._plan is None:
+            raise RuntimeError("MfccExtractor used after close()")
         b = waves.shape[0]
+        if waves.shape[1] != self.n_samp or not waves.is_contiguous():
+            raise ValueError(f"waves must be contiguous [B, {self.n_samp}], got {tuple(waves.shape)}")
+        if waves.dtype == torch.int16:
+            fmt = 1
+        elif waves.dtype == torch.float32:
+            fmt = 0
+        else:
+            raise ValueError(f"waves must be float32 or int16, got {waves.dtype}")
+        if n_valid is not None and (n_valid.dtype != torch.int32 or n_valid.shape[0] != b):
+            raise ValueError("n_valid must be an int32 device tensor [B]")
         if out is None:
             out = torch.empty(b, N_MFCC * utterance_length, device=self.device)
-        N.check(N.lib.lipasr_mfcc_f32(self.h.h, N.ptr(waves), b, utterance_length, N.ptr(mean), N.ptr(scale), N.ptr(out), N.stream_ptr()))
+        N.check(N.lib.lipasr_mfcc_extract(self._plan, N.ptr(waves), fmt, N.ptr(n_valid), b, utterance_length, N.ptr(mean), N.ptr(scale),
+                                          N.ptr(out), N.stream_ptr()))
         return out
 
     def resample(self, waves, out=None):
-        self._own()
         y = torch.empty(waves.shape[0], self.n_y, device=self.device) if out is None else out
-        N.check(N.lib.lipasr_resample_f32(self.h.h, N.ptr(waves), waves.shape[0], N.ptr(y), N.stream_ptr()))
+        N.check(N.lib.lipasr_mfcc_plan_resample(self._plan, N.ptr(waves), waves.shape[0], N.ptr(y), N.stream_ptr()))
         return y
 
     def from_22k(self, y, utterance_length=STANDARD_UTTERANCE_LENGTH, mean=None, scale=None, out=None):
-        self._own()
         if out is None:
             out = torch.empty(y.shape[0], N_MFCC * utterance_length, device=self.device)
-        N.check(N.lib.lipasr_mfcc_from_22k(self.h.h, N.ptr(y), y.shape[0], y.shape[1], utterance_length, N.ptr(mean), N.ptr(scale),
-                                           N.ptr(out), N.stream_ptr()))
+        N.check(N.lib.lipasr_mfcc_plan_from_22k(self._plan, N.ptr(y), y.shape[0], y.shape[1], utterance_length, N.ptr(mean), N.ptr(scale),
+                                                N.ptr(out), N.stream_ptr()))
         return out
 
 
@@ -74,24 +107,41 @@ _extractors = {}
 def _extractor(sr_in, n_samp, batch_max):
     key = (sr_in, n_samp, torch.cuda.current_device())
     ex = _extractors.get(key)
-    if ex is None or ex.batch_max < batch_max:
+    if ex is None or ex.batch_max < batch_max or ex._plan is None or not ex.h.alive:
+        if len(_extractors) >= 8:  # plans hold ~0.1 MB per clip of batch_max: keep a handful
+            _extractors.pop(next(iter(_extractors))).close()
         ex = MfccExtractor(sr_in, n_samp, batch_max)
         _extractors[key] = ex
     return ex
 
 
-def mfcc(waveforms, sr_in=16000, utterance_length=STANDARD_UTTERANCE_LENGTH):
-    """Batched entry: float32 [B, n] (tensor or array) at ``sr_in`` Hz -> device tensor [B, 20*utterance_length]."""
-    w = torch.as_tensor(np.asarray(waveforms, dtype=np.float32) if not torch.is_tensor(waveforms) else waveforms)
-    w = w.to(device=torch.device("cuda", torch.cuda.current_device()), dtype=torch.float32).contiguous()
-    return _extractor(int(sr_in), w.shape[1], w.shape[0])(w, utterance_length)
+def mfcc(waveforms, sr_in=16000, utterance_length=STANDARD_UTTERANCE_LENGTH, n_valid=None):
+    """Batched entry: [B, n] float32 or int16 PCM (tensor or array) at ``sr_in`` Hz -> device tensor [B, 20*utterance_length].
+    n_valid ([B] ints): clips of different lengths, each row zero-padded (or not: the tail is ignored) to n."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    if torch.is_tensor(waveforms):
+        w = waveforms
+    else:
+        a = np.asarray(waveforms)
+        w = torch.as_tensor(a if a.dtype == np.int16 else a.astype(np.float32))
+    if w.dtype != torch.int16:
+        w = w.to(dtype=torch.float32)
+    w = w.to(device=dev).contiguous()
+    nv = None
+    if n_valid is not None:
+        nv = torch.as_tensor(np.asarray(n_valid, dtype=np.int32)).to(dev) if not torch.is_tensor(n_valid) else n_valid.to(device=dev, dtype=torch.int32)
+    return _extractor(int(sr_in), w.shape[1], w.shape[0])(w, utterance_length, n_valid=nv)
 
 
-def read_wav(file_path):
-    """librosa.load's decode + mono mix (float32 in [-1, 1)); returns (samples, sampling_rate)."""
+def read_wav(file_path, pcm16=False):
+    """librosa.load's decode + mono mix (float32 in [-1, 1)); returns (samples, sampling_rate).
+    pcm16=True: a 16-bit mono file comes back as its raw int16 samples (the device scales them by 2^-15 while it stages
+    them, lipasr_mfcc_i16: half the bytes over PCIe and from HBM); any other file still comes back as float32."""
     with wave.open(str(file_path), "rb") as f:
         sr, nch, width, n = f.getframerate(), f.getnchannels(), f.getsampwidth(), f.getnframes()
         raw = f.readframes(n)
+    if pcm16 and width == 2 and nch == 1:
+        return np.frombuffer(raw, dtype="<i2").copy(), sr
     if width == 2:
         x = np.frombuffer(raw, dtype="<i2").astype(np.float32) / 32768.0
     elif width == 1:
@@ -112,19 +162,34 @@ def extract_features(file_path, utterance_length):
     return out.view(N_MFCC, utterance_length).cpu().numpy()
 
 
-def compute_mfcc_all_files(filenames):
-    """Reference :144-150: (N, 880) float64, files of equal length batched through one launch."""
+def compute_mfcc_all_files(filenames, chunk=512):
+    """Reference :144-150: (N, 880) float64.  Files are decoded on the host (16-bit mono files stay int16) and go to the
+    device in chunks of ``chunk`` clips of ANY lengths: one launch per chunk, each clip processed with its own length
+    (n_valid), rows padded to the chunk's longest clip rounded up to a multiple of 4000 samples so that a corpus of
+    one-second clips uses one plan."""
     feats = np.zeros((len(filenames), N_MFCC * STANDARD_UTTERANCE_LENGTH))
-    groups = {}
+    by_sr = {}
     for i, fn in enumerate(filenames):
-        x, sr = read_wav(fn)
-        groups.setdefault((sr, len(x)), []).append((i, x))
-    for (sr, n), items in groups.items():
-        for s in range(0, len(items), 512):
-            chunk = items[s:s + 512]
-            w = np.stack([x for _, x in chunk])
-            f = mfcc(w, sr, STANDARD_UTTERANCE_LENGTH).cpu().numpy()
-            for (i, _), row in zip(chunk, f):
+        x, sr = read_wav(fn, pcm16=True)
+        by_sr.setdefault((sr, x.dtype == np.int16), []).append((i, x))
+    for (sr, is_pcm), items in by_sr.items():
+        ragged_ok = sr in (16000, 8000)  # the fused kernel's rates; other rates: one launch per distinct length
+        if ragged_ok:
+            batches = [items[s:s + chunk] for s in range(0, len(items), chunk)]
+        else:
+            groups = {}
+            for it in items:
+                groups.setdefault(len(it[1]), []).append(it)
+            batches = [g[s:s + chunk] for g in groups.values() for s in range(0, len(g), chunk)]
+        for b in batches:
+            lens = np.array([len(x) for _, x in b], dtype=np.int32)
+            n_max = int(lens.max())
+            n_pad = -(-n_max // 4000) * 4000 if ragged_ok else n_max
+            w = np.zeros((len(b), n_pad), dtype=np.int16 if is_pcm else np.float32)
+            for r, (_, x) in enumerate(b):
+                w[r, :len(x)] = x
+            f = mfcc(w, sr, STANDARD_UTTERANCE_LENGTH, n_valid=lens if ragged_ok else None).cpu().numpy()
+            for (i, _), row in zip(b, f):
                 feats[i] = row
     return feats
 

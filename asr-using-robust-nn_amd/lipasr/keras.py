@@ -384,6 +384,7 @@ class Model:
         N.check(N.lib.lipasr_mlp_create(self._h.h, nb, N.int_array(self._widths), N.int_array(bn), N.float_array(drop),
                                         N.int_array(nonneg), self._max_batch, C.byref(plan)))
         self._plan = plan
+        N.register_owner(self)
         if self._compute_dtype == "bfloat16":
             N.check(N.lib.lipasr_mlp_set_compute(plan, 1))
         n_params, n_state = N.sz(), N.sz()
@@ -409,6 +410,18 @@ class Model:
         self._loss_rows = torch.zeros(self._max_batch, device=dev)
         self._correct_rows = torch.zeros(self._max_batch, device=dev)
         self._init_weights()
+
+    def close(self):
+        """Frees the native classifier plan (its workspace).  Idempotent; the tensors stay readable."""
+        plan, self._plan = getattr(self, "_plan", None), None
+        if plan and self._h.alive:
+            N.lib.lipasr_mlp_destroy(plan)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def _seg(self, i, kind, state=False):
         off, cnt = self._segs[(i, kind)]

@@ -64,6 +64,9 @@ class TrainPipeline:
         self._ev_free = [None] * self._nbuf                             # training has finished reading buffer b
         self._i = 0
         self._graphs = {}
+        self._closed = False
+        self._prof = None
+        N.register_owner(self)
 
     def _make_mfcc_stream(self, mfcc_cus):
         """The MFCC kernels are throughput kernels with thousands of workgroups; the classifier step is a chain of ~30
@@ -112,12 +115,13 @@ class TrainPipeline:
             warnings.warn(f"lipasr: CU-masked stream unavailable ({N.last_error()}); the MFCC stream shares every CU")
             return torch.cuda.Stream(device=self.dev)
         self._masked_stream = st
-        # the persistent resampler sizes its grid to one workgroup per CU it may use
-        N.check(N.lib.lipasr_debug_set(self.h.h, 1, self.mfcc_cus))
+        # the three-kernel path's persistent resampler sizes its grid to one workgroup per CU it may use
+        if hasattr(self.ex, "set"):
+            self.ex.set(1, self.mfcc_cus)
         return torch.cuda.ExternalStream(st.value, device=self.dev)
 
     # ---- pieces (all enqueue on the current stream)
-    def _attack_and_train(self, bsz, b):
+    def _attack_and_train(self, bsz, b, global_batch):
         m = self.model
         x = self._feats2[b][:bsz]
         y = self._labels2[b][:bsz]
@@ -128,7 +132,7 @@ class TrainPipeline:
                 N.check(N.lib.lipasr_mlp_attack_step(m._plan, N.ptr(m._params), N.ptr(m._bnstate), N.ptr(xa), N.ptr(x), N.ptr(y), bsz,
                                                      float(self.pgd.get("eps_step", 0.1)), float(self.pgd["eps"]), N.stream_ptr()))
             x = xa
-        m.train_fwd_bwd(x, y, inv_batch=1.0 / (bsz * self.dp.world))
+        m.train_fwd_bwd(x, y, inv_batch=1.0 / float(global_batch))
 
     def _update(self):
         m = self.model
@@ -158,14 +162,43 @@ class TrainPipeline:
                                                        N.stream_ptr()))
             self._warm = True
 
-    def step(self, waves, y_onehot, features=None):
+    def profile_train(self, n_steps):
+        """Time the classifier part (attack + fwd/bwd [+ all-reduce] + Adam + projection) of the next ``n_steps`` steps with
+        HIP events recorded on the training stream around its launches; ``train_ms()`` returns the mean.  The MFCC of the
+        next batch runs beside it on its own stream, so this is the classifier's time INSIDE the overlapped step."""
+        self._prof = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(int(n_steps))]
+        self._prof_i = 0
+
+    def train_ms(self):
+        used = self._prof[:self._prof_i]
+        self._prof = None
+        if not used:
+            return 0.0
+        used[-1][1].synchronize()
+        return sum(a.elapsed_time(b) for a, b in used) / len(used)
+
+    def step(self, waves, y_onehot, features=None, global_batch=None):
         """waves: float32 device tensor [b, n_samp] (a view into a resident pool is fine), y_onehot [b, classes].
         features: pre-extracted, already standardised [b, 20*L] features instead of waveforms (BASELINE config 2,
-        the reference's own train_constraints.py flow); the MFCC stage is skipped."""
+        the reference's own train_constraints.py flow); the MFCC stage is skipped.
+        global_batch: data parallel with UNEVEN shards only (e.g. the last partial batch cut by ``shard_bounds``): the
+        number of rows all ranks process in this step; default = this rank's rows x world size.
+        Asynchronous: ``pipe.feats`` / ``pipe.labels`` / the model's buffers are valid after ``synchronize()``."""
         bsz = (features if features is not None else waves).shape[0]
+        gb = int(global_batch) if global_batch is not None else bsz * self.dp.world
         b = self._i % self._nbuf
         self._i += 1
         self.feats, self.labels = self._feats2[b], self._labels2[b]
+        if self._closed:
+            raise RuntimeError("TrainPipeline.step() after close()")
+        # the inputs were produced on the caller's stream (an H2D copy, a noise kernel, a slice of a pool): order the
+        # extraction stream after it, and tell the caching allocator that the tensors are in use there so that a
+        # temporary handed to step() is not recycled while the MFCC kernels still read it
+        caller = torch.cuda.current_stream(self.dev)
+        self.mfcc_stream.wait_stream(caller)
+        for t in (waves, y_onehot, features):
+            if t is not None:
+                t.record_stream(self.mfcc_stream)
         with torch.cuda.stream(self.mfcc_stream):
             if self._ev_free[b] is not None:
                 self.mfcc_stream.wait_event(self._ev_free[b])  # the step that last read this buffer is done
@@ -181,22 +214,29 @@ class TrainPipeline:
         with torch.cuda.stream(self.stream):
             self._warm_start()
             self.stream.wait_event(self._ev_feat[b])
+            prof = None
+            if getattr(self, "_prof", None) is not None and self._prof_i < len(self._prof):
+                prof = self._prof[self._prof_i]
+                self._prof_i += 1
+                prof[0].record(self.stream)
             if not self.use_graph:
-                self._attack_and_train(bsz, b)
+                self._attack_and_train(bsz, b, gb)
                 self.dp.allreduce_grads(self.model._grads)
                 self._update()
             else:
-                g = self._graphs.get((bsz, b))
+                g = self._graphs.get((bsz, b, gb))
                 if g is None:
                     if self.dp.world == 1:
-                        g = (self._capture(lambda: (self._attack_and_train(bsz, b), self._update())),)
+                        g = (self._capture(lambda: (self._attack_and_train(bsz, b, gb), self._update())),)
                     else:
-                        g = (self._capture(self._attack_and_train, bsz, b), self._capture(self._update))
-                    self._graphs[(bsz, b)] = g
+                        g = (self._capture(self._attack_and_train, bsz, b, gb), self._capture(self._update))
+                    self._graphs[(bsz, b, gb)] = g
                 N.check(N.lib.lipasr_graph_launch(self.h.h, g[0], N.stream_ptr()))
                 if len(g) == 2:
                     self.dp.allreduce_grads(self.model._grads)
                     N.check(N.lib.lipasr_graph_launch(self.h.h, g[1], N.stream_ptr()))
+            if prof is not None:
+                prof[1].record(self.stream)
             ev = torch.cuda.Event()
             ev.record(self.stream)
             self._ev_free[b] = ev
@@ -211,16 +251,28 @@ class TrainPipeline:
         return "masked" if getattr(self, "_masked_stream", None) is not None else "shared"
 
     def close(self):
-        """Drains both streams and gives the CU-masked stream (a hardware queue of its own) back.  A process that builds
-        several pipelines one after another should close the ones it is done with."""
-        st = getattr(self, "_masked_stream", None)
-        if st is None:
+        """Drains both streams, destroys this pipeline's graph executables and gives the CU-masked stream (a hardware
+        queue of its own) back, in that order.  Idempotent; also reached from ``lipasr._native.shutdown`` at interpreter
+        exit, so no HIP object of the pipeline is left to the runtime's static destructors."""
+        if getattr(self, "_closed", True):
+            return
+        self._closed = True
+        if not self.h.alive:  # the handle went first and took graphs and streams with it
+            self._graphs.clear()
+            self._masked_stream = None
             return
         self.synchronize()
+        for g in self._graphs.values():
+            for gid in g:
+                N.lib.lipasr_graph_destroy(self.h.h, gid)
         self._graphs.clear()
-        self._masked_stream = None
-        self.mfcc_stream = torch.cuda.Stream(device=self.dev)
-        N.lib.lipasr_stream_destroy(self.h.h, st)
+        st = getattr(self, "_masked_stream", None)
+        if st is not None:
+            self._masked_stream = None
+            self.mfcc_stream = torch.cuda.Stream(device=self.dev)
+            N.lib.lipasr_stream_destroy(self.h.h, st)
+        if not self._custom_ex:
+            self.ex.close()  # the pipeline's own MFCC plan
 
     def __del__(self):
         try:

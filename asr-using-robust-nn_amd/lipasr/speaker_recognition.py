@@ -43,30 +43,29 @@ N_SPEAKERS = 20
 
 
 class WindowMfcc:
-    """Plan + launch wrapper for [B, 22050] windows -> [B, 2020] on the short-window MFCC path."""
+    """Plan + launch wrapper for [B, 22050] windows -> [B, 2020] on the short-window MFCC path (a plan of its own:
+    ``MfccExtractor`` with n_fft = win_length = 441, hop 220)."""
 
     def __init__(self, batch_max=512, n_samp=SR, n_fft=N_FFT, hop_length=HOP_LENGTH, device=None):
-        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        self.h = N.get_handle(self.device.index)
+        self._ex = MfccExtractor(SR, n_samp, batch_max, device, n_fft=n_fft, hop=hop_length)
+        self.device, self.h = self._ex.device, self._ex.h
         self.batch_max, self.n_samp, self.n_fft, self.hop = int(batch_max), int(n_samp), int(n_fft), int(hop_length)
-        self._plan()
+        self.n_y, self.n_frames = self._ex.n_y, self._ex.n_frames
 
-    def _plan(self):
-        N.check(N.lib.lipasr_mfcc_plan_ex(self.h.h, SR, self.n_samp, self.batch_max, self.n_fft, self.hop))
-        self.h.mfcc_owner = self
-        ny, nf = C.c_int(), C.c_int()
-        N.check(N.lib.lipasr_mfcc_dims(self.h.h, C.byref(ny), C.byref(nf)))
-        self.n_y, self.n_frames = ny.value, nf.value
+    def set(self, key, value):
+        self._ex.set(key, value)
+
+    def profile_begin(self, n):
+        self._ex.profile_begin(n)
+
+    def profile_end(self):
+        return self._ex.profile_end()
+
+    def close(self):
+        self._ex.close()
 
     def __call__(self, windows, mean=None, scale=None, out=None):
-        if getattr(self.h, "mfcc_owner", None) is not self:
-            self._plan()
-        b = windows.shape[0]
-        if out is None:
-            out = torch.empty(b, N_MFCC * self.n_frames, device=self.device)
-        N.check(N.lib.lipasr_mfcc_from_22k(self.h.h, N.ptr(windows), b, self.n_y, self.n_frames, N.ptr(mean), N.ptr(scale),
-                                           N.ptr(out), N.stream_ptr()))
-        return out
+        return self._ex.from_22k(windows, self.n_frames, mean, scale, out)
 
 
 _window_mfcc = {}

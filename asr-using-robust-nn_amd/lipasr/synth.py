@@ -46,3 +46,31 @@ def synth_clips_fast(n, seed=1234, n_samples=16000, sr=16000):
         s += a * np.sin(2 * np.pi * f[:, j:j + 1] * t + ph[:, j:j + 1])
     w = amp * env * s / 1.75 + 0.01 * rng.standard_normal((n, n_samples)).astype(np.float32)
     return np.clip(w, -1, 1).astype(np.float32), labels
+
+
+def synth_clips_device(n, seed, device, n_samples=16000, sr=16000, chunk=4096):
+    """The same recipe generated on the device with torch (plumbing for the bench's resident pool: 65 536 clips would be
+    4 GB of host arrays and a minute of NumPy).  Returns (waves float32 [n, n_samples], labels int64 [n]) on ``device``.
+    Different random stream than the NumPy generators; same distribution."""
+    import torch
+
+    g = torch.Generator(device=device).manual_seed(int(seed))
+    formants = torch.as_tensor(_FORMANTS, dtype=torch.float32, device=device)
+    t = (torch.arange(n_samples, device=device, dtype=torch.float32) / sr)[None, :]
+    waves = torch.empty(n, n_samples, device=device, dtype=torch.float32)
+    labels = torch.randint(0, 10, (n,), generator=g, device=device)
+    for s in range(0, n, chunk):
+        k = min(chunk, n - s)
+        u = lambda *shape: torch.rand(*shape, generator=g, device=device)
+        f = formants[labels[s:s + k]] * (1.0 + 0.03 * torch.randn(k, 3, generator=g, device=device))
+        amp = 0.1 + 0.4 * u(k, 1)
+        onset = 0.03 + 0.03 * u(k, 1)
+        dur = 0.35 + 0.25 * u(k, 1)
+        ph = 2 * np.pi * u(k, 3)
+        env = ((t - onset) / 0.02).clamp(0, 1) * ((onset + dur - t) / 0.05).clamp(0, 1)
+        sig = torch.zeros(k, n_samples, device=device)
+        for j, a in enumerate((1.0, 0.5, 0.25)):
+            sig += a * torch.sin(2 * np.pi * f[:, j:j + 1] * t + ph[:, j:j + 1])
+        w = amp * env * sig / 1.75 + 0.01 * torch.randn(k, n_samples, generator=g, device=device)
+        waves[s:s + k] = w.clamp(-1, 1)
+    return waves, labels

@@ -47,56 +47,71 @@ def _cpu_mfcc_chunk(args):
     return M.compute_mfcc_batch(args, fast=True)
 
 
-def cpu_baseline(batch, seconds_budget=20.0):
+def cpu_baseline(batch, warmup=5, steps=20):
     """Reference-equivalent CPU path (restated; TF/librosa unavailable offline): per-clip MFCC loop +
-    fp32 train step + simple_norm_constraint with LAPACK SVDs, on the host cores."""
+    fp32 train step + simple_norm_constraint with LAPACK SVDs, on ALL host cores this process may use
+    (>= 5 warm-up + >= 20 timed steps; the count of cores is in the record)."""
     import multiprocessing as mp
 
     from lipasr.synth import synth_clips_fast
     from oracle import constraints_ref as R, mfcc_ref as M, mlp_ref as P
 
-    cores = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
-    waves, labels = synth_clips_fast(batch, seed=99)
+    cores = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    try:  # the train step's GEMMs: OpenBLAS on the same cores
+        from threadpoolctl import threadpool_info, threadpool_limits
+
+        threadpool_limits(limits=cores)
+        blas_threads = max([i.get("num_threads", 1) for i in threadpool_info() if i.get("user_api") == "blas"] or [1])
+    except Exception:
+        blas_threads = None
+    pool_clips = 4 * batch
+    waves, labels = synth_clips_fast(pool_clips, seed=99)
     y = P.to_categorical(labels, 10)
     spec = P.vd_constrained_spec()
     p = P.init_params(spec, seed=0, dtype=np.float32, nonneg_init=True)
     st = P.AdamState()
-    M.compute_mfcc_batch(waves[:2], fast=True)  # builds the cached tables
+    M.compute_mfcc_batch(waves[:2], fast=True)  # builds the cached tables before the fork
     ctx = mp.get_context("fork")
-    steps, t_total, t_mfcc = 0, 0.0, 0.0
+    t_total, t_mfcc = 0.0, 0.0
     with ctx.Pool(cores) as pool:
-        chunks = [waves[i::cores] for i in range(cores)]
-        pool.map(_cpu_mfcc_chunk, [c[:1] for c in chunks])  # warm the workers
-        while t_total < seconds_budget and steps < 4:
+        pool.map(_cpu_mfcc_chunk, [waves[i:i + 1] for i in range(cores)])  # every worker has imported and built its tables
+        for it in range(warmup + steps):
+            s = (it % 4) * batch
+            wb, yb = waves[s:s + batch], y[s:s + batch]
             t0 = time.perf_counter()
-            feats = np.concatenate(pool.map(_cpu_mfcc_chunk, chunks)).astype(np.float32)
+            feats = np.concatenate(pool.map(_cpu_mfcc_chunk, np.array_split(wb, 4 * cores))).astype(np.float32)
             t1 = time.perf_counter()
-            rng = np.random.default_rng(steps)
-            masks = [((rng.uniform(size=(batch, s.n_out)) > s.dropout) / (1 - s.dropout)).astype(np.float32) if s.dropout > 0 else None for s in spec]
-            P.train_step(spec, p, st, feats, y, masks=masks)
+            rng = np.random.default_rng(it)
+            masks = [((rng.uniform(size=(batch, sp.n_out)) > sp.dropout) / (1 - sp.dropout)).astype(np.float32) if sp.dropout > 0 else None for sp in spec]
+            P.train_step(spec, p, st, feats, yb, masks=masks)
             new_w, _ = R.simple_norm_constraint_pass(p.W, 0.1, [])
             p.W = new_w
             t2 = time.perf_counter()
-            steps += 1
-            t_total += t2 - t0
-            t_mfcc += t1 - t0
-    return {"value": round(batch * steps / t_total, 2), "unit": "utterances/sec", "cores": cores, "kind": "port",
-            "sample": f"{steps} steps of batch {batch} (oracle: NumPy MFCC loop over {cores} processes, fp32 NumPy/OpenBLAS train step, "
-                      f"simple_norm_constraint with LAPACK SVD); {t_mfcc / t_total:.0%} of the time in MFCC",
+            if it >= warmup:
+                t_total += t2 - t0
+                t_mfcc += t1 - t0
+    return {"value": round(batch * steps / t_total, 2), "unit": "utterances/sec", "cores": cores, "blas_threads": blas_threads, "kind": "port",
+            "sample": f"{steps} timed steps of batch {batch} after {warmup} warm-up steps ({t_total:.1f} s; oracle: NumPy MFCC loop over {cores} "
+                      f"processes, fp32 NumPy/OpenBLAS train step, simple_norm_constraint with LAPACK SVD); {t_mfcc / t_total:.0%} of the time in MFCC",
             "label": "reference-equivalent CPU path (restated; TensorFlow/librosa unavailable offline)"}
 
 
+POOL_CLIPS = 65536                      # SURVEY 8(d): throughput runs loop a resident pool of >= 65 536 clips per GPU (4.2 GB)
+
+
 def make_pool(n_clips, device, seed):
-    from lipasr.synth import synth_clips_fast
+    """Resident synthetic pool, generated on the device (plumbing): waves [n, 16000] fp32, one-hot labels [n, 10]."""
+    from lipasr.synth import synth_clips_device
 
-    waves, labels = synth_clips_fast(n_clips, seed=seed)
-    y = np.zeros((n_clips, 10), dtype=np.float32)
-    y[np.arange(n_clips), labels] = 1
-    return torch.as_tensor(waves).to(device), torch.as_tensor(y).to(device)
+    waves, labels = synth_clips_device(n_clips, seed, device)
+    y = torch.zeros(n_clips, 10, device=device)
+    y[torch.arange(n_clips, device=device), labels] = 1
+    return waves, y
 
 
-def run_config(args, batch, rank, world, device, steps, warmup, profile):
-    """Builds model + pipeline for one per-GPU batch, times `steps` steps; returns (seconds, extras)."""
+def run_config(opt, pool, batch, rank, world, device, steps, warmup, profile):
+    """Builds model + pipeline for one per-GPU batch, times `steps` steps; returns (seconds, extras).
+    opt: dict(constraint=, pgd=, pgd_eps=, bf16=, pre_extracted=, no_graph=)."""
     import torch.distributed as dist
 
     import lipasr._native as N
@@ -107,10 +122,10 @@ def run_config(args, batch, rank, world, device, steps, warmup, profile):
     from lipasr.pipeline import TrainPipeline
     from lipasr.train_constraints import get_model
 
-    n_batches = 8
-    waves, y = make_pool(n_batches * batch, device, seed=1234 + rank)
+    waves, y = pool
+    n_batches = waves.shape[0] // batch
     # same seed on every rank: replicas start identical
-    model = get_model(max_batch=batch, seed=0, compute_dtype="bfloat16" if args.bf16 else "float32")
+    model = get_model(max_batch=batch, seed=0, compute_dtype="bfloat16" if opt.get("bf16") else "float32")
     model.compile(optimizer="adam", loss=CategoricalCrossentropy(), metrics=["accuracy"])
     # A2 "affine, precomputed": StandardScaler fitted once on MFCCs of the pool
     ex = MfccExtractor(16000, 16000, batch, device)
@@ -119,14 +134,17 @@ def run_config(args, batch, rank, world, device, steps, warmup, profile):
     dp = DataParallel()
     if world > 1:
         dp.broadcast(sc.mean_, sc.scale_, model._params, model._bnstate)
-    pgd = dict(eps=args.pgd_eps, eps_step=0.1, max_iter=args.pgd) if args.pgd > 0 else None
-    pipe = TrainPipeline(model, batch=batch, rho=0.1, constraint=args.constraint, affine=(sc.mean_, sc.scale_), pgd=pgd, dp=dp,
-                         use_graph=not args.no_graph)
+    pgd = dict(eps=opt.get("pgd_eps", 0.5), eps_step=0.1, max_iter=opt["pgd"]) if opt.get("pgd", 0) > 0 else None
+    pipe = TrainPipeline(model, batch=batch, rho=0.1, constraint=opt.get("constraint", "product"), affine=(sc.mean_, sc.scale_), pgd=pgd, dp=dp,
+                         use_graph=not opt.get("no_graph"))
 
-    if os.environ.get("LIPASR_RS_WGS"):
-        N.check(N.lib.lipasr_debug_set(pipe.h.h, 1, int(os.environ["LIPASR_RS_WGS"])))
+    if os.environ.get("LIPASR_MFCC_MASK"):  # A/B runs: 128 = the three-kernel path (resampled signal through HBM)
+        pipe.ex.set(0, int(os.environ["LIPASR_MFCC_MASK"]))
+        ex.set(0, int(os.environ["LIPASR_MFCC_MASK"]))
     feat_pool = None
-    if args.pre_extracted:
+    pre = bool(opt.get("pre_extracted"))
+    if pre:
+        n_batches = min(n_batches, 16)
         feat_pool = torch.cat([ex(waves[i * batch:(i + 1) * batch], 44, sc.mean_, sc.scale_) for i in range(n_batches)])
 
     def one(i):
@@ -143,24 +161,24 @@ def run_config(args, batch, rank, world, device, steps, warmup, profile):
     if world > 1:
         dist.barrier()
     standalone = None
-    if profile and not args.pre_extracted:
-        # the same three kernels alone on the whole chip (untimed, before the measured region): the pipeline confines
+    if profile and not pre:
+        # the same MFCC kernels alone on the whole chip (untimed, before the measured region): the pipeline confines
         # them to a CU share, which lengthens them by design -- both figures are reported
         s_all = torch.cuda.Stream(device=device)
         n_cu = torch.cuda.get_device_properties(device).multi_processor_count
-        N.check(N.lib.lipasr_debug_set(pipe.h.h, 1, n_cu))  # resampler grid for the whole chip
+        pipe.ex.set(1, n_cu)  # (three-kernel path: resampler grid for the whole chip)
         with torch.cuda.stream(s_all):
-            for _ in range(3):
-                pipe.ex(waves[:batch], 44, sc.mean_, sc.scale_, out=pipe._feats2[0][:batch])
+            for k in range(3):
+                pipe.ex(waves[k * batch:(k + 1) * batch], 44, sc.mean_, sc.scale_, out=pipe._feats2[0][:batch])
             s_all.synchronize()
-            N.check(N.lib.lipasr_mfcc_profile_begin(pipe.h.h, 10))
-            for _ in range(10):
-                pipe.ex(waves[:batch], 44, sc.mean_, sc.scale_, out=pipe._feats2[0][:batch])
-            ms3, ncalls = (C.c_float * 3)(), C.c_int()
-            N.check(N.lib.lipasr_mfcc_profile_end(pipe.h.h, ms3, C.byref(ncalls)))
-        standalone = {"resample": round(ms3[0], 4), "stft_mel": round(ms3[1], 4), "dct": round(ms3[2], 4)}
-        N.check(N.lib.lipasr_debug_set(pipe.h.h, 1, getattr(pipe, "mfcc_cus", n_cu)))  # back to the pipeline's CU share
-        N.check(N.lib.lipasr_mfcc_profile_begin(pipe.h.h, steps))
+            pipe.ex.profile_begin(10)
+            for k in range(10):
+                j = (3 + k) % n_batches
+                pipe.ex(waves[j * batch:(j + 1) * batch], 44, sc.mean_, sc.scale_, out=pipe._feats2[0][:batch])
+            ms3, ncalls = pipe.ex.profile_end()
+        standalone = {k: round(v, 4) for k, v in ms3.items()}
+        pipe.ex.set(1, getattr(pipe, "mfcc_cus", n_cu))  # back to the pipeline's CU share
+        pipe.ex.profile_begin(steps)
     tid = C.c_int()
     N.check(N.lib.lipasr_timer_create(pipe.h.h, C.byref(tid)))
     with torch.cuda.stream(pipe.stream):
@@ -177,22 +195,43 @@ def run_config(args, batch, rank, world, device, steps, warmup, profile):
     dt = time.perf_counter() - t0
     ev_ms = C.c_float()
     N.check(N.lib.lipasr_timer_elapsed_ms(pipe.h.h, tid.value, C.byref(ev_ms)))
-    extras = {"event_ms_per_step": ev_ms.value / steps, "final_norm": float(pipe.norms[-1].item()) if args.constraint == "product" else None,
+    extras = {"event_ms_per_step": ev_ms.value / steps, "final_norm": float(pipe.norms[-1].item()) if opt.get("constraint", "product") == "product" else None,
               "loss": float(model._loss_rows[:batch].mean().item())}
-    if profile and args.pre_extracted:
+    if profile and pre:
         extras["mfcc_ms"] = {"resample": 0.0, "stft_mel": 0.0, "dct": 0.0, "calls": 0}
     elif profile:
-        ms3 = (C.c_float * 3)()
-        n = C.c_int()
-        N.check(N.lib.lipasr_mfcc_profile_end(pipe.h.h, ms3, C.byref(n)))
-        extras["mfcc_ms"] = {"resample": ms3[0], "stft_mel": ms3[1], "dct": ms3[2], "calls": n.value}
+        ms3, n = pipe.ex.profile_end()
+        extras["mfcc_ms"] = dict(ms3, calls=n)
+    extras["mfcc_fused"] = bool(getattr(pipe.ex, "fused", False)) and not os.environ.get("LIPASR_MFCC_MASK")
+    # the classifier part of the step, timed on ITS stream while the MFCC of the next batch runs beside it (untimed extra
+    # steps after the measured region, so that the two event records per step do not touch `value`)
+    n_prof = min(20, steps)
+    pipe.profile_train(n_prof)
+    for i in range(n_prof):
+        one(warmup + steps + i)
+    pipe.synchronize()
+    extras["train_graph_ms"] = pipe.train_ms()
     extras["mfcc_standalone_ms"] = standalone
     extras["mfcc_cus"] = getattr(pipe, "mfcc_cus", None)
     extras["mfcc_stream"] = pipe.mfcc_stream_kind
     extras["n_cus"] = torch.cuda.get_device_properties(device).multi_processor_count
+    extras["pool_clips"] = int(n_batches * batch)
     assert np.isfinite(extras["loss"]), "training diverged"
-    pipe.close()  # the masked stream is a hardware queue: hand it back before the next configuration builds its own
+    pipe.close()  # graphs, then the masked stream (a hardware queue): handed back before the next configuration builds its own
+    model.close()
+    ex.close()
     return dt, extras
+
+
+def _short(opt, pool, batch, rank, world, device, steps, warmup):
+    """One secondary configuration as a small record (value, ms per step, classifier TFLOP/s where it applies)."""
+    dt, ex = run_config(opt, pool, batch, rank, world, device, steps, warmup, profile=False)
+    rec = {"value": round(batch * steps / dt, 1), "unit": "utterances/sec", "ms_per_step": round(dt / steps * 1e3, 4), "per_gpu_batch": batch,
+           "steps": steps, "dtype": "bf16 operands, f32 accumulate" if opt.get("bf16") else "f32",
+           "train_graph_ms": round(ex["train_graph_ms"], 4), "mfcc_stream": ex.get("mfcc_stream")}
+    if not opt.get("pgd"):
+        rec["classifier_tflops"] = round(TRAIN_FLOP_PER_UTT * batch / (ex["train_graph_ms"] * 1e-3) / 1e12, 2)
+    return rec
 
 
 def main():
@@ -201,6 +240,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch-per-gpu", type=int, default=1024)
+    ap.add_argument("--pool-clips", type=int, default=POOL_CLIPS, help="resident waveform pool per GPU (SURVEY 8d: >= 65536)")
     ap.add_argument("--constraint", default="product", choices=["product", "per_layer", "none"])
     ap.add_argument("--pgd", type=int, default=0, help="PGD iterations per batch (config 5 uses 20)")
     ap.add_argument("--pgd-eps", type=float, default=0.5)
@@ -210,9 +250,10 @@ def main():
     ap.add_argument("--pre-extracted", action="store_true", help="BASELINE config 2: train from resident (N,880) features, no MFCC stage")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--skip-b512", action="store_true")
+    ap.add_argument("--skip-other-configs", action="store_true", help="do not add the config 2 / config 2 bf16 / config 5 records (N = 1 only)")
     args = ap.parse_args()
-    if args.constraint == "none":
-        args.constraint = None
+    opt = {"constraint": None if args.constraint == "none" else args.constraint, "pgd": args.pgd, "pgd_eps": args.pgd_eps, "bf16": args.bf16,
+           "pre_extracted": args.pre_extracted, "no_graph": args.no_graph}
 
     from lipasr.parallel import init_from_env
 
@@ -226,7 +267,8 @@ def main():
     import torch.distributed as dist
 
     batch = args.batch_per_gpu
-    dt, ex = run_config(args, batch, rank, world, device, args.steps, args.warmup, profile=True)
+    pool = make_pool(max(args.pool_clips, 8 * batch) // batch * batch, device, seed=1234 + rank)
+    dt, ex = run_config(opt, pool, batch, rank, world, device, args.steps, args.warmup, profile=True)
     t = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -243,16 +285,21 @@ def main():
     dom = max(("resample", "stft_mel", "dct"), key=lambda k: ms[k])
     achieved = MFCC_BYTES_PER_UTT * batch / (stage_ms * 1e-3) / 1e9 if stage_ms > 0 else 0.0
     # HBM traffic of the stage per launch: PMC counters cannot be read from inside this process, so the value is
-    # the committed rocprofv3 measurement of the same three kernels (profiles/r02_mfcc_pmc.json: separate
-    # --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per MI355X_MICROARCH.md), scaled to this batch.
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r02_mfcc_pmc.json")) as f:
-            traffic = round(json.load(f)["end_of_round"]["stage_bytes_per_utt"] * batch)
-    except Exception:
-        pass
+    # the committed rocprofv3 measurement of the same kernels (separate --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH
+    # doubled per MI355X_MICROARCH.md), scaled to this batch.
+    traffic, traffic_src = None, None
+    for name in ("r03_mfcc_pmc.json", "r02_mfcc_pmc.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                traffic = round(json.load(f)["end_of_round"]["stage_bytes_per_utt"] * batch)
+            traffic_src = f"profiles/{name} (rocprofv3 --pmc, per launch, scaled by batch)"
+            break
+        except Exception:
+            continue
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": traffic, "traffic_source": "profiles/r02_mfcc_pmc.json (rocprofv3 --pmc, per launch, scaled by batch)", "stage": "MFCC (K1 = resample + stft_mel + dct kernels)", "dominant_kernel": dom + "_kernel",
+                "traffic": traffic, "traffic_source": traffic_src,
+                "stage": "MFCC (K1 = mfcc_fused_kernel [resample + STFT + mel + dB, timed in the stft_mel slot] + dct_kernel)" if ex.get("mfcc_fused") else "MFCC (K1 = resample + stft_mel + dct kernels)",
+                "dominant_kernel": ("mfcc_fused" if ex.get("mfcc_fused") and dom == "stft_mel" else dom) + "_kernel",
                 "algorithmic_bytes_per_utt": MFCC_BYTES_PER_UTT, "units_per_launch": batch,
                 "kernel_ms": {k: round(ms[k], 4) for k in ("resample", "stft_mel", "dct")},
                 "fp32_flop_frac": round(MFCC_FLOP_PER_UTT * batch / (stage_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 5) if stage_ms > 0 else 0.0,
@@ -269,6 +316,7 @@ def main():
         sa_ach = MFCC_BYTES_PER_UTT * batch / (sa_ms * 1e-3) / 1e9
         roofline["standalone_whole_chip"] = {"kernel_ms": sa, "achieved": round(sa_ach, 2), "frac": round(sa_ach / HBM_PEAK_GBS, 5),
                                              "fp32_flop_frac": round(MFCC_FLOP_PER_UTT * batch / (sa_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 5)}
+    cls_tflops = TRAIN_FLOP_PER_UTT * batch / (ex["train_graph_ms"] * 1e-3) / 1e12 if not args.pgd and ex["train_graph_ms"] > 0 else None
     if args.pre_extracted:
         tf = TRAIN_FLOP_PER_UTT * batch / (ex["event_ms_per_step"] * 1e-3) / 1e12
         roofline = {"bound": "mfma", "achieved": round(tf, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP32_PEAK_TFLOPS, 5),
@@ -282,16 +330,28 @@ def main():
                                   + " -> Lipschitz-constrained MLP train step (Adam+NonNeg, simple_norm_constraint rho=0.1)" + (f" + PGD-{args.pgd} adversarial inner loop" if args.pgd else "")
                                   + (", data-parallel RCCL gradient all-reduce" if world > 1 else ", 1xMI355X"),
                       "baseline_config": 5 if args.pgd else (2 if args.pre_extracted else (4 if world > 1 else 3)), "global_batch": global_batch, "per_gpu_batch": batch,
-                      "clip": "1 s @ 16 kHz fp32", "parallelism": f"dp{world}", "hip_graph": not args.no_graph},
+                      "clip": "1 s @ 16 kHz fp32", "resident_pool_clips_per_gpu": ex["pool_clips"], "parallelism": f"dp{world}", "hip_graph": not args.no_graph},
            "roofline": roofline, "mfcc_stream": ex.get("mfcc_stream"),
-           "mlp_tflops": round(TRAIN_FLOP_PER_UTT * batch / max(1e-9, (ex["event_ms_per_step"] - stage_ms) * 1e-3) / 1e12, 3),
+           # the classifier's part of the step (attack + fwd/bwd [+ all-reduce] + Adam + projection), HIP events on the training
+           # stream while the next batch's MFCC runs on its own stream; TFLOP/s = 9.59 MFLOP/utt x batch / that time
+           "train_graph_ms": round(ex["train_graph_ms"], 4), "classifier_tflops": round(cls_tflops, 2) if cls_tflops else None,
+           "classifier_fp32_mfma_frac": round(cls_tflops / FP32_PEAK_TFLOPS, 4) if cls_tflops else None,
            "event_ms_per_step": round(ex["event_ms_per_step"], 4), "final_product_norm": ex["final_norm"], "loss": round(ex["loss"], 4)}
     if world == 1 and not args.skip_b512 and batch != 512:
-        dt5, ex5 = run_config(args, 512, rank, world, device, args.steps, args.warmup, profile=True)
+        dt5, ex5 = run_config(opt, pool, 512, rank, world, device, args.steps, args.warmup, profile=True)
         out["reference_batch_512"] = {"value": round(512 * args.steps / dt5, 1), "ms_per_step": round(dt5 / args.steps * 1e3, 4),
                                       "mfcc_ms": {k: round(v, 4) for k, v in ex5["mfcc_ms"].items() if k != "calls"},
-                                      "mfcc_stream": ex5.get("mfcc_stream")}
+                                      "train_graph_ms": round(ex5["train_graph_ms"], 4), "mfcc_stream": ex5.get("mfcc_stream")}
+    if world == 1 and not args.skip_other_configs and not (args.pgd or args.pre_extracted or args.bf16):
+        # the other single-GPU BASELINE configurations, in the driver-run record (short runs; each is its own model + pipeline)
+        k, w = min(args.steps, 50), min(args.warmup, 10)
+        base = {"constraint": "product"}
+        out["reference_config_2_pre_extracted_f32"] = _short({**base, "pre_extracted": True}, pool, batch, rank, world, device, k, w)
+        out["reference_config_2_pre_extracted_bf16"] = _short({**base, "pre_extracted": True, "bf16": True}, pool, batch, rank, world, device, k, w)
+        out["reference_config_5_pgd20_1gpu"] = _short({**base, "pgd": 20, "pgd_eps": 0.5}, pool, batch, rank, world, device, min(k, 20), min(w, 5))
     if world == 1 and not args.skip_cpu_baseline:
+        del pool
+        torch.cuda.empty_cache()
         out["cpu_baseline"] = cpu_baseline(512)
     else:
         out["cpu_baseline"] = None

@@ -47,6 +47,7 @@ extern "C" {
 
 typedef struct lipasr_ctx* lipasr_handle_t;
 typedef struct lipasr_mlp* lipasr_mlp_t;
+typedef struct lipasr_mfcc* lipasr_mfcc_t;
 typedef void* lipasr_stream_t; /* hipStream_t */
 
 /* ------------------------------------------------------------------ core */
@@ -297,12 +298,47 @@ int lipasr_mfcc_from_22k(lipasr_handle_t h, const float* y, int batch, int n_y, 
                          const double* affine_mean, const double* affine_scale, float* out,
                          lipasr_stream_t stream);
 
+/* 16-bit PCM input (the corpus is 16-bit PCM wav, extract_features_construct_dataset.py:27: librosa.load
+ * decodes to float32 by a 2^-15 scale) and clips of DIFFERENT lengths in one launch
+ * (compute_mfcc_all_files, :144-150, loops files of any length): pcm is [batch][n_samp] int16 where
+ * n_samp is the plan's sample count; n_valid (device int [batch], may be NULL = n_samp everywhere) gives
+ * the samples of each row that belong to the clip.  Clip u is processed exactly as a plan of
+ * n_valid[u] samples would process it alone (resampled length, frame count, reflect padding and the
+ * top_db maximum follow its own length; frames past its end are the zero columns of :33-37).  Same
+ * bits as lipasr_mfcc_f32 on pcm * 2^-15.  Needs the fused 2048/512 path (16 kHz / 8 kHz input);
+ * otherwise LIPASR_EUNSUPPORTED. */
+int lipasr_mfcc_i16(lipasr_handle_t h, const int16_t* pcm, const int* n_valid, int batch,
+                    int utterance_length, const double* affine_mean, const double* affine_scale,
+                    float* out, lipasr_stream_t stream);
+
+/* MFCC plans as objects: each owns its tables and intermediates, so several extractors (a training
+ * pipeline's and a validation pass's, or two streams) coexist on one handle without re-planning.
+ * The handle-level entry points above operate on the handle's default plan.
+ * sample_format: 0 = float32 in [-1, 1), 1 = int16 PCM.  n_valid as in lipasr_mfcc_i16. */
+int lipasr_mfcc_create(lipasr_handle_t h, int sr_in, int n_samp_max, int batch_max, int n_fft, int hop,
+                       lipasr_mfcc_t* out);
+int lipasr_mfcc_destroy(lipasr_mfcc_t p);
+/* fused (may be NULL): 1 when the plan runs resampling and STFT as ONE kernel (the resampled signal stays in LDS) */
+int lipasr_mfcc_plan_dims(lipasr_mfcc_t p, int* n_y, int* n_frames, int* fused);
+int lipasr_mfcc_extract(lipasr_mfcc_t p, const void* wav, int sample_format, const int* n_valid, int batch,
+                        int utterance_length, const double* affine_mean, const double* affine_scale,
+                        float* out, lipasr_stream_t stream);
+int lipasr_mfcc_plan_resample(lipasr_mfcc_t p, const float* wav, int batch, float* y, lipasr_stream_t stream);
+int lipasr_mfcc_plan_from_22k(lipasr_mfcc_t p, const float* y, int batch, int n_y, int utterance_length,
+                              const double* affine_mean, const double* affine_scale, float* out,
+                              lipasr_stream_t stream);
+
 /* Per-kernel HIP-event timing of the next `max_calls` extractions -- lipasr_mfcc_f32 calls, or
  * lipasr_resample_f32 + lipasr_mfcc_from_22k pairs -- recorded on the stream the kernels run on.
  * _end synchronises and returns the average milliseconds of {resample, stft_mel, dct}
- * (host float[3]) and the number of extractions measured (host int). */
+ * (host float[3]) and the number of extractions measured (host int).  On the fused path there is no
+ * resampling kernel: slot 0 is 0 and slot 1 is the fused resample + STFT + mel kernel. */
 int lipasr_mfcc_profile_begin(lipasr_handle_t h, int max_calls);
 int lipasr_mfcc_profile_end(lipasr_handle_t h, float* avg_ms3, int* n_calls);
+int lipasr_mfcc_plan_profile_begin(lipasr_mfcc_t p, int max_calls);
+int lipasr_mfcc_plan_profile_end(lipasr_mfcc_t p, float* avg_ms3, int* n_calls);
+/* knobs of one plan: keys as lipasr_debug_set */
+int lipasr_mfcc_plan_set(lipasr_mfcc_t p, int key, int value);
 
 /* A12 audio-domain noise on device, Philox RNG (attacks.py:73-86, 145-183, 222-245), in place on
  * y [batch][n]:  mode 0: y + N(0, p0)               (add_white_noise, sigma = p0)
@@ -311,8 +347,10 @@ int lipasr_mfcc_profile_end(lipasr_handle_t h, float* avg_ms3, int* n_calls);
 int lipasr_add_noise_f32(lipasr_handle_t h, float* y, int batch, int n, int mode, float p0, float p1,
                          uint64_t seed, lipasr_stream_t stream);
 
-/* Knobs.  key 0: MFCC stage mask for profiling (bit0 skip the FFT passes, bit1 skip the mel reduction -- both give
- * wrong results and exist to time the remaining stages; bit2 selects the VALU resampler instead of the MFMA one).
+/* Knobs of the handle's default MFCC plan.  key 0: stage mask for profiling (bit0 skip the FFT passes, bit1 skip the mel
+ * reduction -- both give wrong results and exist to time the remaining stages; bit2 selects the VALU resampler instead of
+ * the MFMA one; bit7 (128) selects the three-kernel path -- resample, STFT, DCT with the resampled signal in HBM -- instead
+ * of the fused resample -> STFT kernel: the parity reference of the fused kernel).
  * key 1: number of workgroups the persistent resampler aims for = the CUs its stream may use (default 256; a
  * pipeline that runs the MFCC on a CU-masked stream sets it to the size of the mask).  Kept in the handle. */
 int lipasr_debug_set(lipasr_handle_t h, int key, int value);

@@ -71,3 +71,24 @@ def dev(x, device="cuda"):
 def rel_err(a, b):
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def _oracle_mfcc_chunk(chunk):
+    from oracle import mfcc_ref as M
+
+    return M.compute_mfcc_batch(chunk)
+
+
+def oracle_mfcc_parallel(waves, workers=None):
+    """oracle.mfcc_ref.compute_mfcc_batch (the exact resampler, ~0.1 s per clip) over a process pool.  `spawn`: the
+    parent may hold a HIP context, which must not be forked."""
+    import multiprocessing as mp
+    import os
+
+    n = len(waves)
+    workers = workers or max(1, min(16, len(os.sched_getaffinity(0)), (n + 15) // 16))
+    if workers == 1:
+        return _oracle_mfcc_chunk(waves)
+    chunks = np.array_split(np.asarray(waves), workers * 4)
+    with mp.get_context("spawn").Pool(workers) as pool:
+        return np.concatenate(pool.map(_oracle_mfcc_chunk, [c for c in chunks if len(c)]))

@@ -126,3 +126,141 @@ def test_mfcc_needs_plan_and_validates(cuda):
     N.check(N.lib.lipasr_mfcc_plan(h, 16000, 16000, 2))
     assert N.lib.lipasr_mfcc_f32(h, N.ptr(w), 3, 44, None, None, N.ptr(out), N.stream_ptr()) == N.EINVAL  # batch > plan
     N.check(N.lib.lipasr_destroy(h))
+
+
+# ------------------------------------------------------------------ round 3: fused resample -> STFT kernel, int16 PCM, ragged batches
+def test_fused_kernel_equals_three_kernel_path(cuda):
+    """mfcc_fused_kernel (resampled signal in LDS, 16x16x4 MFMA rows = q-blocks of one clip) against the round-2 path
+    (resample_persist -> HBM -> stft_mel), same plan, stage-mask bit 7.  Both resamplers run the same ascending-k fp32 fma
+    chain, so the difference is the FFT twiddles (table values vs products of table values): ~1e-5 in MFCC units."""
+    from lipasr.extract_features_construct_dataset import MfccExtractor
+    from lipasr.synth import synth_clips
+
+    waves, _ = synth_clips(40, seed=11)
+    ex = MfccExtractor(16000, 16000, 64)
+    assert ex.fused
+    a = ex(dev(waves)).cpu().numpy()
+    ex.set(0, 128)
+    b = ex(dev(waves)).cpu().numpy()
+    ex.set(0, 0)
+    c = ex(dev(waves)).cpu().numpy()
+    assert np.array_equal(a, c)  # deterministic
+    assert np.abs(a - b).max() < 2e-3, np.abs(a - b).max()
+    ref = M.compute_mfcc_batch(waves[:8])
+    assert np.abs(a[:8] - ref).max() < ATOL and np.abs(b[:8] - ref).max() < ATOL
+
+
+@pytest.mark.parametrize("sr_in,n", [(16000, 16000), (8000, 8000), (16000, 24000), (16000, 5003)])
+def test_fused_kernel_other_rates_and_lengths(cuda, sr_in, n):
+    from lipasr.extract_features_construct_dataset import MfccExtractor
+
+    rng = np.random.default_rng(n)
+    t = np.arange(n) / sr_in
+    w = (0.3 * np.sin(2 * np.pi * (300 + 200 * np.arange(5)[:, None]) * t) + 0.05 * rng.standard_normal((5, n))).astype(np.float32)
+    ex = MfccExtractor(sr_in, n, 8)
+    assert ex.fused
+    got = ex(dev(w), 50).cpu().numpy()
+    ref = M.compute_mfcc_batch(w, sr_in=sr_in, utterance_length=50)
+    assert np.abs(got - ref).max() < ATOL, np.abs(got - ref).max()
+
+
+def test_int16_pcm_input_is_bit_identical(cuda):
+    """lipasr_mfcc_i16 / sample_format 1: the device scales by 2^-15 while staging, which is exactly the host conversion
+    (extract_features_construct_dataset.py:27, librosa.load's decode of 16-bit PCM)."""
+    from lipasr.extract_features_construct_dataset import MfccExtractor
+    from lipasr.synth import synth_clips
+
+    waves, _ = synth_clips(19, seed=3)
+    pcm = np.clip(np.round(waves * 32768.0), -32768, 32767).astype(np.int16)
+    ex = MfccExtractor(16000, 16000, 32)
+    a = ex(torch.as_tensor(pcm).cuda())
+    b = ex(dev(pcm.astype(np.float32) / 32768.0))
+    assert torch.equal(a, b)
+    assert np.abs(a.cpu().numpy() - M.compute_mfcc_batch(pcm.astype(np.float32) / 32768.0)).max() < ATOL
+    # an unaligned row length (no vector loads) and the handle-level C entry point
+    import ctypes as C
+
+    from lipasr import _native as N
+
+    odd = pcm[:, :15999].copy()
+    exo = MfccExtractor(16000, 15999, 32)
+    assert torch.equal(exo(torch.as_tensor(odd).cuda()), exo(dev(odd.astype(np.float32) / 32768.0)))
+    h = N.get_handle(0)
+    N.check(N.lib.lipasr_mfcc_plan(h.h, 16000, 16000, 32))
+    out = torch.empty(19, 880, device="cuda")
+    N.check(N.lib.lipasr_mfcc_i16(h.h, N.ptr(torch.as_tensor(pcm).cuda()), None, 19, 44, None, None, N.ptr(out), N.stream_ptr()))
+    assert torch.equal(out, a)
+
+
+def test_ragged_batch_equals_per_clip_launches(cuda):
+    """Clips of different lengths in ONE launch (compute_mfcc_all_files loops files of any length,
+    extract_features_construct_dataset.py:144-150): clip u with n_valid[u] samples comes out exactly as a plan made
+    for that length produces it alone -- resampled length, frame count, reflect padding, the top_db maximum and the zero
+    columns past its last frame.  Garbage beyond n_valid in a row must not matter."""
+    from lipasr.extract_features_construct_dataset import MfccExtractor
+    from lipasr.synth import synth_clips
+
+    waves, _ = synth_clips(12, seed=9)
+    lens = np.array([16000, 15999, 12345, 8000, 7430, 4096, 2049, 1025, 700, 37, 2, 16000], dtype=np.int32)
+    rng = np.random.default_rng(0)
+    padded = waves.copy()
+    for i, n in enumerate(lens):
+        padded[i, n:] = rng.standard_normal(16000 - n)  # not zeros: the tail is outside the clip
+    ex = MfccExtractor(16000, 16000, 16)
+    sc_mean = torch.as_tensor(rng.standard_normal(880)).cuda()
+    sc_scale = torch.as_tensor(rng.uniform(0.5, 2.0, 880)).cuda()
+    got = ex(dev(padded), n_valid=torch.as_tensor(lens).cuda())
+    got_aff = ex(dev(padded), 44, sc_mean, sc_scale, n_valid=torch.as_tensor(lens).cuda())
+    for i, n in enumerate(lens):
+        one = MfccExtractor(16000, int(n), 1)
+        alone = one(dev(waves[i:i + 1, :n]))
+        assert torch.equal(got[i:i + 1], alone), (i, n, float((got[i:i + 1] - alone).abs().max()))
+        assert torch.equal(got_aff[i:i + 1], one(dev(waves[i:i + 1, :n]), 44, sc_mean, sc_scale)), (i, n)
+        ref = M.compute_mfcc_batch(waves[i:i + 1, :n])
+        assert np.abs(got[i:i + 1].cpu().numpy() - ref).max() < ATOL, (i, n)
+        one.close()
+    # int16 + ragged together, and through the module-level entry
+    from lipasr.extract_features_construct_dataset import mfcc
+
+    pcm = np.clip(np.round(padded * 32768.0), -32768, 32767).astype(np.int16)
+    a = mfcc(pcm, 16000, n_valid=lens)
+    b = mfcc(pcm.astype(np.float32) / 32768.0, 16000, n_valid=lens)
+    assert torch.equal(a, b)
+    # zero-length rows: no frame at all -> the zero columns of fix_frames
+    z = ex(dev(padded[:2]), n_valid=torch.as_tensor(np.array([0, 1], np.int32)).cuda())
+    assert torch.count_nonzero(z) == 0
+
+
+def test_ragged_and_int16_need_the_fused_path(cuda):
+    from lipasr.extract_features_construct_dataset import MfccExtractor
+
+    ex = MfccExtractor(44100, 4410, 4)  # a down-sampling rate: three-kernel path only
+    assert not ex.fused
+    w = torch.zeros(2, 4410, device="cuda")
+    ex(w)
+    with pytest.raises(Exception):
+        ex(w, n_valid=torch.full((2,), 4000, dtype=torch.int32, device="cuda"))
+    with pytest.raises(Exception):
+        ex(torch.zeros(2, 4410, dtype=torch.int16, device="cuda"))
+
+
+def test_two_extractors_do_not_share_state(cuda):
+    """one MFCC plan per handle made alternating extractors re-plan on every call; plans are objects now."""
+    from lipasr.extract_features_construct_dataset import MfccExtractor
+    from lipasr.synth import synth_clips
+
+    waves, _ = synth_clips(8, seed=1)
+    a, b = MfccExtractor(16000, 16000, 8), MfccExtractor(16000, 8000, 8)
+    fa = a(dev(waves))
+    fb = b(dev(waves[:, :8000].copy()))
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s1):
+        fa2 = a(dev(waves))
+    with torch.cuda.stream(s2):
+        fb2 = b(dev(waves[:, :8000].copy()))
+    torch.cuda.synchronize()
+    assert torch.equal(fa, fa2) and torch.equal(fb, fb2)
+    a.close(); b.close()
+    with pytest.raises(Exception):
+        a(dev(waves))

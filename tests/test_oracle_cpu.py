@@ -469,3 +469,52 @@ def test_mfcc_after_resampling_equals_transformers_plus_scipy(n_fft, hop, n):
     assert np.abs(got - want).max() <= 2e-3
     got64 = M.mfcc_22k(y.astype(np.float64), np.float64, n_fft, hop)
     assert np.abs(got64 - want).max() <= 5e-5  # float64 inside, returned as float32 (values up to ~170: ulp 1.5e-5)
+
+
+# The resampler against SciPy's polyphase FIR machinery.  resampy's kaiser_best interpolator evaluates, for every output
+# sample at input-time tau, sum_n x[n] w(tau - n) with w = the linearly interpolated half window.  For the rational ratio
+# L/M every tau - n is a multiple of 1/L, so the whole resampler IS scipy.signal.upfirdn(g, x, up=L, down=M) with the
+# prototype g[j] = w(|j - C| / L): the filter here comes from np.interp on the window table (not from the oracle's tap
+# gather code), and the filtering from SciPy's compiled upfirdn (not from the oracle's index arithmetic).
+def _kaiser_best_prototype(L):
+    win, num_table = M.kaiser_best_half_window()
+    C = M.KB_NUM_ZEROS * L
+    j = np.arange(-C + 1, C)                                  # |d| < 64 zero crossings
+    pos = np.abs(j) / L * num_table                           # position in the 512-per-crossing window table
+    g = np.interp(pos, np.arange(len(win)), win)
+    # resampy's tap count i_max = (len(win) - int(frac * 512)) // 512 keeps the 64th tap of a wing only while the
+    # table offset is 0 or 1: the support ends at table position 63 * 512 + 2 (the dropped taps are ~3e-8)
+    g[pos >= (M.KB_NUM_ZEROS - 1) * num_table + 2] = 0.0
+    return g, C - 1                                           # taps, index of the centre tap
+
+
+@pytest.mark.parametrize("sr_in,n", [(16000, 16000), (16000, 5003), (8000, 8000), (11025, 3000)])
+def test_resampler_equals_scipy_upfirdn(sr_in, n):
+    g_ = int(np.gcd(sr_in, 22050))
+    L, Mdown = 22050 // g_, sr_in // g_
+    x = np.random.default_rng(n).standard_normal(n)
+    g, centre = _kaiser_best_prototype(L)
+    # upfirdn returns v[Mdown * i] of v = g * upsample(x); y[t] = v[Mdown * t + centre]: shift the centre onto the grid
+    lead = (-centre) % Mdown
+    out = scipy.signal.upfirdn(np.concatenate([np.zeros(lead), g]), x, up=L, down=Mdown)
+    skip = (centre + lead) // Mdown
+    n_out = int(n * (22050.0 / sr_in))
+    ref = out[skip:skip + n_out]
+    for mode in ("accumulate", "multiply"):
+        got = M.resample_kaiser_best(x, sr_in, 22050, time_mode=mode).astype(np.float64)
+        # float32 rounding of the oracle's output is all that separates them
+        assert got.shape == ref.shape and np.abs(got - ref).max() < 2e-7 * max(1.0, np.abs(ref).max()), mode
+    fast = M.resample_kaiser_best_fast(x, sr_in, 22050).astype(np.float64)
+    assert np.abs(fast - ref).max() < 2e-7 * max(1.0, np.abs(ref).max())
+
+
+def test_polyphase_table_equals_prototype_slices():
+    """The per-phase taps (what the GPU resampler contracts with) are strided slices of the same prototype."""
+    h, n_off, L, Mdown, wing = M._polyphase_table(16000, 22050)
+    g, centre = _kaiser_best_prototype(L)
+    gz = np.concatenate([np.zeros(L), g, np.zeros(L)])   # taps just outside the 64-crossing support are zero
+    for p in (0, 1, 17, 220, 440):
+        # output L q + p sits at input time M q + p M / L; tap k multiplies x[M q + n_off[p] - (wing - 1) + k]
+        k = np.arange(2 * wing)
+        j = p * Mdown - (n_off[p] - (wing - 1) + k) * L     # (tau - n) * L
+        np.testing.assert_allclose(h[p], gz[L + centre + j], rtol=0, atol=1e-15)

@@ -90,6 +90,7 @@ def test_pipeline_matches_oracle_training_steps(cuda):
     pipe = TrainPipeline(m, batch=32, rho=0.1, constraint="product", use_graph=True)
     p64, st = p.astype(np.float64), P.AdamState()
     ref_feats = M.compute_mfcc_batch(waves)
+    solid = [None] * 6
     for s in range(0, 96, 32):
         pipe.step(dev(waves[s:s + 32]), dev(y[s:s + 32]))
         pipe.synchronize()
@@ -97,7 +98,14 @@ def test_pipeline_matches_oracle_training_steps(cuda):
         assert np.abs(feats - ref_feats[s:s + 32]).max() < 2e-2
         # the oracle steps from the checked device features: Adam turns a sign flip of a ~1e-7 gradient
         # into a 1e-3 move, which would measure MFCC rounding rather than the step's arithmetic
-        P.train_step(spec, p64, st, feats, y[s:s + 32].astype(np.float64))
+        out = P.train_step(spec, p64, st, feats, y[s:s + 32].astype(np.float64))
+        # Adam's first steps move a weight by ~lr * sign(g): where |g| is at rounding level its sign -- and with it a
+        # 1e-3-sized move -- is not determined.  Entries whose oracle gradient stayed clear of that level in every step
+        # are held to the tight bound, the undetermined rest only to the size of the moves themselves.
+        for l in range(6):
+            g = np.abs(out["dW"][l])
+            ok = g > 1e-3 * g.max()  # GPU dW agrees to 5e-5 of the max (test_mlp_gpu): >= 20x clear of a sign flip
+            solid[l] = ok if solid[l] is None else (solid[l] & ok)
         new_w, norms = R.simple_norm_constraint_pass([w.astype(np.float32) for w in p64.W], 0.1, [])
         p64.W = [w.astype(np.float64) for w in new_w]
     pipe.synchronize()
@@ -105,6 +113,8 @@ def test_pipeline_matches_oracle_training_steps(cuda):
     np.testing.assert_allclose(pipe.norms.cpu().numpy(), norms, rtol=2e-3)
     for l in range(6):
         d = np.abs(after.W[l] - p64.W[l]) / np.abs(p64.W[l]).max()
+        assert solid[l].mean() > 0.05, (l, solid[l].mean())
+        assert d[solid[l]].max() < 2e-3, (l, d[solid[l]].max())
         assert np.quantile(d, 0.999) < 2e-3 and d.max() < 5e-2, (l, np.quantile(d, 0.999), d.max())
 
 

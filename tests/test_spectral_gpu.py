@@ -192,6 +192,35 @@ def test_fista_surface(cuda):
         assert rel_err(l.w, r) < 2e-3  # fp32 products + GPU SVD vs the float64 host iteration
 
 
+def test_fista_reference_size(cuda):
+    """The reference's own setting (train_constraints.py:100: norm_constraint_FISTA(rho=5, nit=2)) on the reference's
+    kernels 880-1024-512-256-128-64-10, against the float64 host iteration of oracle.constraints_ref.fista_pass
+    (Constraints.py:54-130 line by line); also the wall time of one on_batch_end, for DESIGN.md."""
+    import time
+
+    from lipasr.Constraints import norm_constraint_FISTA
+
+    ws = inputs.nonneg_kernels(inputs.FULL_WIDTHS, seed=4)
+    ref = R.fista_pass(ws, 5.0, 2)
+    model = FakeModel(ws)
+    cb = norm_constraint_FISTA(rho=5.0, nit=2)
+    cb.set_model(model)
+    cb.on_batch_end(0)
+    dense = [l for l in model.layers if "dense" in l.name]
+    errs = [rel_err(l.w, r) for l, r in zip(dense, ref)]
+    moved = [rel_err(r, w) for r, w in zip(ref, ws)]
+    assert max(moved) > 1e-2  # the pass is not a no-op at this size
+    assert max(errs) < 2e-3, errs
+    # a second pass from the projected kernels (the callback runs after every batch): its wall time
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    cb.on_batch_end(1)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert all(np.isfinite(l.w).all() and l.w.min() >= 0 for l in dense)
+    print(f"\nFISTA rho=5 nit=2 at 880-1024-512-256-128-64-10: max rel err {max(errs):.2e}, one on_batch_end {dt * 1e3:.1f} ms")
+
+
 def test_lip_readouts_on_native_model(cuda):
     from helpers import build_model, load_params
     from lipasr.extract_features_construct_dataset import get_lipschitz_constrained, get_norms, get_upper_lipschitz

@@ -1,0 +1,54 @@
+"""GPU: deterministic teardown (DESIGN "exit-time SIGSEGV").  A child process builds a TrainPipeline on the
+CU-masked stream, replays its graphs and exits WITHOUT close(): lipasr's atexit teardown must leave rc 0.  The profiled
+variant of the same probe (the configuration that crashed in round 2) is run once per round by hand:
+profiles/r03_exit_probe.txt."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_exit_without_close_is_clean(cuda):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scratch", "exit_probe.py")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    assert "exit_probe: stream=" in r.stdout
+
+
+def test_close_releases_graphs_and_stream(cuda):
+    import numpy as np
+
+    import lipasr._native as N
+    from helpers import build_model, dev
+    from lipasr.pipeline import TrainPipeline
+    from lipasr.synth import synth_clips
+    from oracle import mlp_ref as P
+
+    spec = P.vd_constrained_spec()
+    m = build_model(spec, max_batch=32)
+    waves, labels = synth_clips(32, seed=5)
+    pipe = TrainPipeline(m, batch=32, rho=0.1, use_graph=True)
+    pipe.step(dev(waves), dev(P.to_categorical(labels, 10)))
+    pipe.synchronize()
+    gids = [g for gs in pipe._graphs.values() for g in gs]
+    assert gids
+    pipe.close()
+    pipe.close()  # idempotent
+    assert pipe.mfcc_stream_kind == "shared" and not pipe._graphs
+    # the executables are gone on the native side: launching one is an argument error, not a crash
+    assert N.lib.lipasr_graph_launch(pipe.h.h, gids[0], N.stream_ptr()) == N.EINVAL
+    with pytest.raises(RuntimeError):
+        pipe.step(dev(waves), dev(P.to_categorical(labels, 10)))
+    # a second pipeline on the same handle works after the first was closed
+    pipe2 = TrainPipeline(m, batch=32, rho=0.1, use_graph=True)
+    pipe2.step(dev(waves), dev(P.to_categorical(labels, 10)))
+    pipe2.synchronize()
+    assert torch.isfinite(m._params).all()
+    pipe2.close()
+    m.close()
+    m.close()
