@@ -41,7 +41,8 @@ struct MfccPlan {
   // fused resample -> STFT kernel (mfcc_fused_kernel): frame groups of a clip of n_samp samples, {q0, f_begin, f_end, 0}
   int* d_groups = nullptr;
   int n_groups = 0;
-  bool fused = false;
+  bool fused = false;         // the plan CAN run the fused kernel
+  bool prefer_fused = false;  // ... and uses it for plain float32 batches too (lipasr_mfcc_plan_set key 2)
   float* d_hann = nullptr;
   float* d_tw = nullptr;  // float2 [2048]
   float* d_twB = nullptr; // float2 [32 r][32 k]: exp(-2 pi i r k / 1024) (pass B of the wave FFT)
@@ -606,6 +607,257 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(StftArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// stage 2, dual form (round 3): one workgroup = one clip x FOUR frames = two complex FFTs (A = frames f0 + i f1,
+// B = f2 + i f3) evaluated by the same threads in lock step, the pair (A, B) in the two halves of every packed-fp32
+// operand.  stft_mel_kernel keeps (re, im) of ONE FFT in a packed operand, and half of its vector instructions are the
+// half-swaps, negations and moves complex arithmetic needs in that layout (112 v_mov + 57 v_cndmask against 285
+// packed math instructions, 686 per wavefront in all).  With (A, B) packed, a complex product is two v_pk_mul + two
+// v_pk_fma on plain registers, x(-i) is a register renaming, and one address computation serves both FFTs: about a third
+// of the vector instructions per frame.  LDS: one float4 {reA, reB, imA, imB} per point, index e + (e >> 4) (one float4 of
+// padding per 16): every access of the four passes is `per-thread base + compile-time offset` -- the XOR swizzle of
+// stft_mel_kernel cost three integer instructions per access -- unit-stride ds_read_b128 are conflict-free, and so is the
+// stride-8 scatter of pass 1 (8 lanes -> 8 x 4 distinct banks).  34.9 kB + 4 kB per workgroup: four workgroups per CU.
+// The two mel weights of a bin multiply the four frames' powers at once (float4 {f0, f2, f1, f3}).
+// ---------------------------------------------------------------------------------------------
+template <int R>
+__device__ __forceinline__ void load_tw(const float2* __restrict__ tw, int j, int Ns, cpx (&w)[R - 1]);
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+struct cp2 { v2f re, im; };
+__device__ __forceinline__ cp2 add2(cp2 a, cp2 b) { return {a.re + b.re, a.im + b.im}; }
+__device__ __forceinline__ cp2 sub2(cp2 a, cp2 b) { return {a.re - b.re, a.im - b.im}; }
+__device__ __forceinline__ cp2 mulw(cp2 a, cpx w) { return {a.re * w.re - a.im * w.im, a.re * w.im + a.im * w.re}; }
+__device__ __forceinline__ cp2 mmi2(cp2 a) { return {a.im, -a.re}; }  // a * (-i)
+
+__device__ __forceinline__ void dft8_2(cp2 (&v)[8]) {
+  const float s = 0.70710678118654752440f;
+  cp2 a0 = add2(v[0], v[4]), a1 = sub2(v[0], v[4]), a2 = add2(v[2], v[6]), a3 = mmi2(sub2(v[2], v[6]));
+  cp2 a4 = add2(v[1], v[5]), a5 = sub2(v[1], v[5]), a6 = add2(v[3], v[7]), a7 = mmi2(sub2(v[3], v[7]));
+  cp2 b0 = add2(a0, a2), b2 = sub2(a0, a2), b1 = add2(a1, a3), b3 = sub2(a1, a3);
+  cp2 b4 = add2(a4, a6), b6 = sub2(a4, a6), b5 = add2(a5, a7), b7 = sub2(a5, a7);
+  cp2 t5 = {(b5.re + b5.im) * s, (b5.im - b5.re) * s};
+  cp2 t6 = mmi2(b6);
+  cp2 t7 = {(b7.im - b7.re) * s, (-b7.re - b7.im) * s};
+  v[0] = add2(b0, b4); v[4] = sub2(b0, b4);
+  v[1] = add2(b1, t5); v[5] = sub2(b1, t5);
+  v[2] = add2(b2, t6); v[6] = sub2(b2, t6);
+  v[3] = add2(b3, t7); v[7] = sub2(b3, t7);
+}
+__device__ __forceinline__ void dft4_2(cp2 (&v)[4]) {
+  cp2 a0 = add2(v[0], v[2]), a1 = sub2(v[0], v[2]), a2 = add2(v[1], v[3]), a3 = mmi2(sub2(v[1], v[3]));
+  v[0] = add2(a0, a2); v[2] = sub2(a0, a2); v[1] = add2(a1, a3); v[3] = sub2(a1, a3);
+}
+
+constexpr int kF2Buf = 2 * 1028 + 8;  // float4 elements: 2048 points, or the two weighted-power arrays of 1025 bins
+constexpr int kF2TP = 1028;                    // stride of the two weighted-power arrays laid over the buffer
+__device__ __forceinline__ float4 ld4(const float4* p) { return *p; }
+__device__ __forceinline__ void st4(float4* p, cp2 v) { *p = make_float4(v.re.x, v.re.y, v.im.x, v.im.y); }
+__device__ __forceinline__ cp2 tocp2(float4 t) { return {v2f{t.x, t.y}, v2f{t.z, t.w}}; }
+
+// Radix-8 Stockham pass of the dual FFT.  rbase / wbase: this thread's padded float4 index of element 0 of its reads
+// and writes; the other seven are compile-time offsets (RO(r), WO(r)).
+#define LP_F2_PASS8(RO, WO, TW, FIRST)                                                    \
+  {                                                                                        \
+    cp2 v[8];                                                                              \
+    if (FIRST) {                                                                           \
+      _Pragma("unroll") for (int r = 0; r < 8; ++r) v[r] = x0[r];                          \
+    } else {                                                                               \
+      _Pragma("unroll") for (int r = 0; r < 8; ++r) v[r] = tocp2(ld4(rd + (RO(r))));       \
+      lds_barrier2();                                                                      \
+      _Pragma("unroll") for (int r = 1; r < 8; ++r) v[r] = mulw(v[r], TW[r - 1]);          \
+    }                                                                                      \
+    dft8_2(v);                                                                             \
+    _Pragma("unroll") for (int r = 0; r < 8; ++r) st4(wr + (WO(r)), v[r]);                 \
+  }
+
+__device__ __forceinline__ void lds_barrier2() {
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): LDS traffic only (the kernel's global stores need no ordering)
+  __builtin_amdgcn_s_barrier();
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void stft_mel2_kernel(StftArgs a) {
+  __shared__ __attribute__((aligned(16))) float4 buf[kF2Buf];
+  __shared__ __attribute__((aligned(16))) float4 rsum[2][128];  // run sums {f0, f2, f1, f3}: [weight array][run]
+  __shared__ float wmax[4][2];
+  const int tid = threadIdx.x, lane = tid & 63;
+  // XCD-aware block -> (clip, frame quad) map, as in stft_mel_kernel
+  int u, fq;
+  {
+    const int nq = gridDim.x, L = blockIdx.y * gridDim.x + blockIdx.x, nb = gridDim.y;
+    const int full = (nb / 8) * 8 * nq;
+    if (L < full) {
+      const int chunk = L >> 3;
+      u = (chunk / nq) * 8 + (L & 7);
+      fq = chunk % nq;
+    } else {
+      u = blockIdx.y;
+      fq = blockIdx.x;
+    }
+  }
+  const int f0 = 4 * fq;
+  const float* yu = a.y + (size_t)u * a.n_y;
+  // per-thread constants (L2-resident tables), on their way before the sample loads
+  const int mel_part = (tid >> 6) & 1, mel_run = ((tid >> 7) << 6) + lane;
+  const int mst = a.mel_start[mel_run], mln = a.mel_len[mel_run];
+  float hw[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) hw[e] = a.hann[tid + 256 * e];
+  // twiddles of passes 2 and 3 leave now (their L2 round trip hides behind the sample loads and pass 1); those of pass 4 and
+  // the mel weights are requested one pass ahead of their use.  The barriers below wait for LDS traffic only.
+  cpx w2[7], w3[7];
+  load_tw<8>(a.tw, tid, 8, w2);
+  load_tw<8>(a.tw, tid, 64, w3);
+  cp2 x0[8];
+  if (f0 >= 2 && f0 + 3 < a.n_frames && (f0 + 3) * 512 + 1024 <= a.n_y) {
+    // all four frames inside the clip: frame j is frame 0 moved by 2 j of the thread's 256-sample steps
+    const float* p = yu + (f0 * 512 - 1024) + tid;
+    float sm[14];
+#pragma unroll
+    for (int e = 0; e < 14; ++e) sm[e] = p[256 * e];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x0[e] = {v2f{hw[e] * sm[e], hw[e] * sm[e + 4]}, v2f{hw[e] * sm[e + 2], hw[e] * sm[e + 6]}};
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int j0 = f0 * 512 + tid + 256 * e - 1024;
+      float sj[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sj[j] = (f0 + j < a.n_frames) ? yu[reflect_index(j0 + 512 * j, a.n_y)] : 0.0f;
+      x0[e] = {v2f{hw[e] * sj[0], hw[e] * sj[2]}, v2f{hw[e] * sj[1], hw[e] * sj[3]}};
+    }
+  }
+  // ---- four passes.  Element e lives at float4 index swz(e) = e ^ (((e >> 4) & 3) << 1): inside every aligned block
+  // of 16 float4 (one 256-byte bank row) a permutation, so unit-stride ds_read_b128 stay conflict-free in the hardware's
+  // lane groups, and the stride-8 scatter of pass 1 spreads its 8-lane store groups over 8 different bank quads
+  // (scratch/lds_model.py; additive padding made every read 2-way: 29 % of the LDS cycles of the first version).
+  // Bits 4-5 of e are bits 4-5 of the thread index for every read and for the writes of passes 3 and 4, so those
+  // addresses are `per-thread base + compile-time offset`; passes 1 and 2 pay one v_xor per store.
+  const int sx = ((tid >> 4) & 3) << 1;
+  const int tsw = tid ^ sx;  // swz(tid + 256 r) = tsw + 256 r
+  {
+    // pass 1 (Ns = 1): butterfly j = tid writes e = 8 j + r: bits 4-5 of e = bits 1-2 of j
+    float4* wr = buf + 8 * tid;
+    const int s1 = ((tid >> 1) & 3) << 1;
+    const float4* rd = buf;  // (unused: pass 1 takes its inputs from registers)
+#define LP_RO1(r) 0
+#define LP_WO1(r) ((r) ^ s1)
+    const cpx* none = nullptr;
+    LP_F2_PASS8(LP_RO1, LP_WO1, none, true)
+#undef LP_RO1
+#undef LP_WO1
+  }
+  lds_barrier2();
+  {
+    // pass 2 (Ns = 8): reads tid + 256 r; writes e = 64 (j >> 3) + k + 8 r: bits 4-5 of e = r >> 1, so the xor value
+    // 2 (r >> 1) is a compile-time constant applied to k = j & 7
+    const float4* rd = buf + tsw;
+    const int k = tid & 7;
+    float4* wr = buf + 64 * (tid >> 3);
+#define LP_RO2(r) (256 * (r))
+#define LP_WO2(r) (8 * (r) + (k ^ (((r) >> 1) << 1)))
+    LP_F2_PASS8(LP_RO2, LP_WO2, w2, false)
+#undef LP_WO2
+  }
+  cpx wa[3], wb[3];
+  load_tw<4>(a.tw, tid, 512, wa);
+  load_tw<4>(a.tw, tid + 256, 512, wb);
+  lds_barrier2();
+  {
+    // pass 3 (Ns = 64): writes e = 512 (j >> 6) + k + 64 r, k = j & 63: bits 4-5 of e = bits 4-5 of k
+    const float4* rd = buf + tsw;
+    const int k = tid & 63;
+    float4* wr = buf + 512 * (tid >> 6) + (k ^ (((k >> 4) & 3) << 1));
+#define LP_WO3(r) (64 * (r))
+    LP_F2_PASS8(LP_RO2, LP_WO3, w3, false)
+#undef LP_WO3
+#undef LP_RO2
+  }
+  float mwl[5], mwh[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int kb = tid + 256 * i;
+    mwl[i] = (kb <= 1024) ? a.mel_wlo[kb] : 0.0f;
+    mwh[i] = (kb <= 1024) ? a.mel_whi[kb] : 0.0f;
+  }
+  lds_barrier2();
+  // pass 4 (Ns = 512, radix 4): butterflies j = tid and tid + 256 read and write e = j + 512 r.  Its outputs are the
+  // spectrum in natural order: bin tid + 256 i of this thread is va[i / 2] (i even) or vb[i / 2] (i odd)
+  cp2 va[4], vb[4];
+  {
+    float4* pa = buf + tsw;
+    float4* pb = pa + 256;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { va[r] = tocp2(ld4(pa + 512 * r)); vb[r] = tocp2(ld4(pb + 512 * r)); }
+    lds_barrier2();
+#pragma unroll
+    for (int r = 1; r < 4; ++r) { va[r] = mulw(va[r], wa[r - 1]); vb[r] = mulw(vb[r], wb[r - 1]); }
+    dft4_2(va);
+    dft4_2(vb);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { st4(pa + 512 * r, va[r]); st4(pb + 512 * r, vb[r]); }
+  }
+  lds_barrier2();
+  // ---- separation by conjugate symmetry, powers, the two mel weights of each bin.  Z[k] is in registers (above); the
+  // partner Z[2048 - k] belongs to another thread and comes from LDS.
+  float4 zc[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int kb = tid + 256 * i;
+    if (kb <= 1024) {
+      const int kc = (2048 - kb) & 2047;
+      zc[i] = buf[kc ^ (((kc >> 4) & 3) << 1)];
+    }
+  }
+  lds_barrier2();
+  float4* T = buf;  // Tlo[k] at k, Thi[k] at kF2TP + k: {f0, f2, f1, f3} x weight
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int kb = tid + 256 * i;
+    if (kb <= 1024) {
+      const cp2 z = (i & 1) ? vb[i >> 1] : va[i >> 1];
+      const v2f zr = z.re, zi = z.im, cr = {zc[i].x, zc[i].y}, ci = {-zc[i].z, -zc[i].w};
+      const v2f x0r = 0.5f * (zr + cr), x0i = 0.5f * (zi + ci), x1r = 0.5f * (zi - ci), x1i = -0.5f * (zr - cr);
+      const v2f p0 = x0r * x0r + x0i * x0i, p1 = x1r * x1r + x1i * x1i;  // {f0, f2}, {f1, f3}
+      T[kb] = make_float4(mwl[i] * p0.x, mwl[i] * p0.y, mwl[i] * p1.x, mwl[i] * p1.y);
+      T[kF2TP + kb] = make_float4(mwh[i] * p0.x, mwh[i] * p0.y, mwh[i] * p1.x, mwh[i] * p1.y);
+    }
+  }
+  lds_barrier2();
+  // ---- mel run sums: one lane per (weight array, run), all four frames per load
+  {
+    const float4* Tp = T + mel_part * kF2TP + mst;
+    v2f s0 = {0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    int i = 0;
+    for (; i + 2 <= mln; i += 2) {
+      const float4 t0 = Tp[i], t1 = Tp[i + 1];
+      s0 += v2f{t0.x, t0.y}; s1 += v2f{t0.z, t0.w};
+      s2 += v2f{t1.x, t1.y}; s3 += v2f{t1.z, t1.w};
+    }
+    if (i < mln) { const float4 t0 = Tp[i]; s0 += v2f{t0.x, t0.y}; s1 += v2f{t0.z, t0.w}; }
+    s0 += s2; s1 += s3;
+    rsum[mel_part][mel_run] = make_float4(s0.x, s0.y, s1.x, s1.y);
+  }
+  lds_barrier2();
+  // ---- mel = run(m) of Tlo + run(m - 1) of Thi; thread (pair, m) finishes frames f0 + 2 pair and f0 + 2 pair + 1
+  const int pr = tid >> 7, m = tid & 127;
+  float4 sum = rsum[0][m];
+  if (m > 0) { const float4 h2 = rsum[1][m - 1]; sum.x += h2.x; sum.y += h2.y; sum.z += h2.z; sum.w += h2.w; }
+  const float se = pr ? sum.y : sum.x, so = pr ? sum.w : sum.z;  // even / odd frame of the pair
+  const float dbe = 10.0f * log10f(fmaxf(1e-10f, se)), dbo = 10.0f * log10f(fmaxf(1e-10f, so));
+  const int fe = f0 + 2 * pr, fo = fe + 1;
+  if (fe < a.n_frames) a.db[((size_t)u * a.n_frames + fe) * 128 + m] = dbe;
+  if (fo < a.n_frames) a.db[((size_t)u * a.n_frames + fo) * 128 + m] = dbo;
+  const float me = wave_max(dbe), mo = wave_max(dbo);
+  if (lane == 0) { wmax[tid >> 6][0] = me; wmax[tid >> 6][1] = mo; }
+  lds_barrier2();
+  if (tid < 4) {
+    const int f = f0 + tid, w0 = 2 * (tid >> 1), c = tid & 1;
+    if (f < a.n_frames) a.fmax[(size_t)u * a.n_frames + f] = fmaxf(wmax[w0][c], wmax[w0 + 1][c]);
+  }
+}
+#undef LP_F2_PASS8
+
+// ---------------------------------------------------------------------------------------------
 // stage 2, wave-synchronous form: ONE wavefront per frame pair, no workgroup barrier anywhere.
 //   2048 = 32 x 32 x 2.  Each lane holds 32 complex points in registers:
 //     pass A  radix-32 butterfly on x[lane + 64 r]                      -> LDS [32 lane + q]
@@ -984,7 +1236,10 @@ __device__ __forceinline__ void fft_pass_regs(float2* __restrict__ buf, int Ns, 
       v[r] = {t.x, t.y};
     }
   }
-  if (!regs) __syncthreads();
+  if (!regs) {  // LDS-only barrier (see lds_barrier below)
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();
+  }
   if (Ns > 1) {
 #pragma unroll
     for (int r = 1; r < R; ++r) v[r] = cmul(v[r], w[r - 1]);
@@ -1004,6 +1259,14 @@ __device__ __forceinline__ void load_tw(const float2* __restrict__ tw, int j, in
     const float2 t = tw[(r * tstep) & 2047];
     w[r - 1] = {t.x, t.y};
   }
+}
+
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding global access of the
+// wave (vmcnt(0)) -- inside the frame loop that would expose the dB stores of the previous pair (a round trip to L2) at
+// the next pair's first barrier, once per pair.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+  __builtin_amdgcn_s_barrier();
 }
 
 template <bool I16>
@@ -1077,7 +1340,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   {
     const int ir = lane & 15, kk = lane >> 4;
     const float* xrow = xs + (down + 2) * ir;
-    for (int r = wave; r < a.n_ptiles; r += 4) {
+    for (int r = wave; r < ((a.st.stage_mask & 512) ? 0 : a.n_ptiles); r += 4) {  // (bit 9: profiling, skips the resampling)
       const int lo_r = a.lo[r];
       const float* hb = a.Hband + (size_t)r * kRsBand * 32 + kk * 32 + ir;
       float b0[kRsBand / 4], b1[kRsBand / 4];
@@ -1113,6 +1376,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
   }
   __syncthreads();
+  if (a.st.stage_mask & 256) return;  // (bit 8: profiling, stops before the frames)
   // ---- 3. the frame pairs of the group, from LDS
   const StftArgs& st = a.st;
   const int ybase = kFuUp * q0;
@@ -1120,11 +1384,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   float hw[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) hw[e] = st.hann[tid + 256 * e];
-  cpx w2[7], w3[7], w4a[3], w4b[3];
-  load_tw<8>(st.tw, tid, 8, w2);
+  cpx w3[7];
   load_tw<8>(st.tw, tid, 64, w3);
-  load_tw<4>(st.tw, tid, 512, w4a);
-  load_tw<4>(st.tw, tid + 256, 512, w4b);
   const int mel_part = (tid >> 6) & 1, mel_run = ((tid >> 7) << 6) + (tid & 63);
   const int mst = st.mel_start[mel_run], mln = st.mel_len[mel_run];
   float mwl[5], mwh[5];
@@ -1141,6 +1402,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     // hoisted out of the loop as invariants those ~90 addresses would push the per-thread tables into scratch.
     int tq = tid;
     asm volatile("" : "+v"(tq));
+    // (the twiddles of passes 2 and 4 are fetched per pair, from the L2-resident table, at the top of the iteration: keeping them
+    // resident as well pushed 15 registers per lane into scratch -- 63 MB of scratch traffic per 1024 clips)
+    cpx w2[7], w4a[3], w4b[3];
+    load_tw<8>(st.tw, tq, 8, w2);
+    load_tw<4>(st.tw, tq, 512, w4a);
+    load_tw<4>(st.tw, tq + 256, 512, w4b);
     cpx x0[8];
     if (has1 && f0 >= 2 && f1 * 512 + 1024 <= n_y) {
       const float* p = ys + (f0 * 512 - 1024 - ybase) + tq;
@@ -1161,11 +1428,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     {
       const cpx none7[7] = {};
       fft_pass_regs<8>(buf, 1, tq, none7, x0);
-      __syncthreads();
+      lds_barrier();
       fft_pass_regs<8>(buf, 8, tq, w2, nullptr);
-      __syncthreads();
+      lds_barrier();
       fft_pass_regs<8>(buf, 64, tq, w3, nullptr);
-      __syncthreads();
+      lds_barrier();
       // radix 4, two butterflies per thread: both read, the workgroup meets, both write
       cpx va[4], vb[4];
 #pragma unroll
@@ -1174,7 +1441,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         va[r] = {ta.x, ta.y};
         vb[r] = {tb.x, tb.y};
       }
-      __syncthreads();
+      lds_barrier();
 #pragma unroll
       for (int r = 1; r < 4; ++r) { va[r] = cmul(va[r], w4a[r - 1]); vb[r] = cmul(vb[r], w4b[r - 1]); }
       dft4(va);
@@ -1185,7 +1452,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         buf[padi(tq + r * 512)] = make_float2(va[r].re, va[r].im);
         buf[padi(tq + 256 + r * 512)] = make_float2(vb[r].re, vb[r].im);
       }
-      __syncthreads();
+      lds_barrier();
     }
     float2 zz[5], zc[5];
 #pragma unroll
@@ -1196,7 +1463,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         zc[i] = buf[padi((2048 - k) & 2047)];
       }
     }
-    __syncthreads();
+    lds_barrier();
     float2* T = buf;
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
@@ -1210,7 +1477,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         T[kTPair + k] = make_float2(mwh[i] * p0, mwh[i] * p1);
       }
     }
-    __syncthreads();
+    lds_barrier();
     const int sel = tq >> 7, m = tq & 127;
     {
       const float2* Tp = T + mel_part * kTPair + mst;
@@ -1224,7 +1491,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       for (; i < mln; ++i) { const float2 v = Tp[i]; a0.x += v.x; a0.y += v.y; }
       rsum[mel_part * 128 + mel_run] = make_float2((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y));
     }
-    __syncthreads();
+    lds_barrier();
     const float* rs = reinterpret_cast<const float*>(rsum);
     const float sacc = rs[2 * m + sel] + ((m > 0) ? rs[2 * (128 + m - 1) + sel] : 0.0f);
     const float dbv = 10.0f * log10f(fmaxf(1e-10f, sacc));  // librosa.power_to_db(ref=1, amin=1e-10)
@@ -1232,7 +1499,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     if (f < fe) st.db[((size_t)u * st.n_frames + f) * 128 + m] = dbv;
     const float wm = wave_max(dbv);
     if (lane == 0) wmax[tq >> 6] = wm;
-    __syncthreads();
+    lds_barrier();
     if (tq == 0) st.fmax[(size_t)u * st.n_frames + f0] = fmaxf(wmax[0], wmax[1]);
     if (tq == 128 && has1) st.fmax[(size_t)u * st.n_frames + f1] = fmaxf(wmax[2], wmax[3]);
   }
@@ -1535,6 +1802,8 @@ static int launch_from_22k(const MfccPlan* p, const float* y, int batch, int L, 
       LP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dft_mel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)dl));
     hipLaunchKernelGGL(dft_mel_kernel, dim3((d.total_rows + kDftRows - 1) / kDftRows), dim3(64 * p->dft_tiles), dl, st, d);
+  } else if (!(p->stage_mask & (32 | 64 | 3))) {
+    hipLaunchKernelGGL(stft_mel2_kernel, dim3((p->n_frames + 3) / 4, batch), dim3(256), 0, st, a);
   } else if (!(p->stage_mask & 32)) {
     hipLaunchKernelGGL(stft_mel_kernel, dim3((p->n_frames + 1) / 2, batch), dim3(256), 0, st, a);
   } else {
@@ -1720,8 +1989,9 @@ static int plan_run(MfccPlan* p, const void* wav, int fmt, const int* n_valid, i
   LP_CHECK_ARG(wav && out, "lipasr_mfcc: null argument");
   LP_CHECK_ARG(fmt == 0 || fmt == 1, "lipasr_mfcc: sample format %d (0 = float32, 1 = int16 PCM)", fmt);
   LP_CHECK_ARG((am == nullptr) == (as == nullptr), "lipasr_mfcc: give both affine arrays or neither");
-  const bool fused = p->fused && !(p->stage_mask & 128);
-  if (!fused && (fmt != 0 || n_valid)) {
+  const bool can_fuse = p->fused && !(p->stage_mask & 128);
+  const bool fused = can_fuse && (p->prefer_fused || fmt != 0 || n_valid != nullptr);
+  if (!can_fuse && (fmt != 0 || n_valid)) {
     set_error("lipasr_mfcc: int16 input and per-clip lengths need the fused 2048/512 path (16 kHz or 8 kHz input); this plan is %d Hz, n_fft %d",
               p->sr_in, p->n_fft);
     return LIPASR_EUNSUPPORTED;
@@ -1790,7 +2060,11 @@ static int plan_profile_end(MfccPlan* p, float* avg_ms3, int* n_calls) {
 
 static int plan_set(MfccPlan* p, int key, int value) {
   LP_CHECK_ARG(p != nullptr, "lipasr_mfcc_set: null plan");
-  LP_CHECK_ARG(key == 0 || key == 1, "lipasr_mfcc_set: unknown key %d", key);
+  LP_CHECK_ARG(key >= 0 && key <= 2, "lipasr_mfcc_set: unknown key %d", key);
+  if (key == 2) {
+    p->prefer_fused = value != 0;
+    return LIPASR_OK;
+  }
   if (key == 1) {
     LP_CHECK_ARG(value >= 1 && value <= 4096, "lipasr_mfcc_set: resampler workgroup target %d", value);
     p->rs_target_wgs = value;
@@ -1949,7 +2223,7 @@ int lipasr_add_noise_f32(lipasr_handle_t h, float* y, int batch, int n, int mode
  * the three-kernel path aims for. */
 int lipasr_debug_set(lipasr_handle_t h, int key, int value) {
   LP_CHECK_ARG(h != nullptr, "lipasr_debug_set: null handle");
-  LP_CHECK_ARG(key == 0 || key == 1, "lipasr_debug_set: unknown key %d", key);
+  LP_CHECK_ARG(key >= 0 && key <= 2, "lipasr_debug_set: unknown key %d", key);
   if (!h->mfcc) { set_error("lipasr_debug_set: call lipasr_mfcc_plan first"); return LIPASR_ESTATE; }
   int rc = plan_set(h->mfcc, key, value);
   if (rc == LIPASR_OK && key == 1) h->rs_target_wgs = value;  // kept in the handle: a later lipasr_mfcc_plan inherits it

@@ -53,7 +53,8 @@ class MfccExtractor:
             pass
 
     def set(self, key, value):
-        """lipasr_mfcc_plan_set: key 0 = stage mask (128 = three-kernel path), key 1 = resampler workgroups."""
+        """lipasr_mfcc_plan_set: key 0 = stage mask (64 = round-2 STFT kernel, 128 = never fuse), key 1 = resampler workgroups,
+        key 2 = 1: the fused resample -> STFT kernel for every batch (default: only for int16 / ragged input)."""
         N.check(N.lib.lipasr_mfcc_plan_set(self._plan, int(key), int(value)))
 
     def profile_begin(self, max_calls):

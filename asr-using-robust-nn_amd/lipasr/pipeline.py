@@ -26,14 +26,19 @@ from .parallel import DataParallel
 
 class TrainPipeline:
     def __init__(self, model, batch, sr_in=16000, n_samp=16000, utterance_length=44, rho=0.1, constraint="product",
-                 affine=None, pgd=None, dp=None, use_graph=True, per_layer_iters=4, extractor=None, mfcc_cus="auto"):
+                 affine=None, pgd=None, dp=None, use_graph=True, per_layer_iters=4, extractor=None, mfcc_cus="auto", sync_inputs=True):
         """constraint: 'product' (simple_norm_constraint, all layers), 'per_layer' (norm_constraint) or None.
         affine: (mean, scale) float64 device tensors [20*utterance_length] or None.
         pgd: dict(eps=, eps_step=, max_iter=) for adversarial training on the standardised features.
         extractor: a feature extractor ``f(waves, mean, scale, out=)`` replacing the 2048/512 MFCC plan, e.g.
         ``speaker_recognition.WindowMfcc`` (441/220 windows -> 2020 features; pass utterance_length=101).
         mfcc_cus: how many of the GPU's CUs the feature-extraction stream may use (a CU-masked HIP stream, spread
-        evenly over the XCDs); "auto" = the measured best share, None / 0 = no mask."""
+        evenly over the XCDs); "auto" = the measured best share, None / 0 = no mask.
+        sync_inputs: order the extraction stream after the caller's current stream and the caller's stream after the
+        extraction (two event hand-offs per step, ~50 us of a 0.4 ms step).  Needed whenever the tensors handed to step()
+        were just produced on the caller's stream or are temporaries; a loop over a resident pool that was filled and
+        synchronised beforehand (bench.py) may pass False."""
+        self.sync_inputs = bool(sync_inputs)
         self.model, self.batch, self.L = model, int(batch), int(utterance_length)
         self.dev = model._device
         self.h = N.get_handle(self.dev.index)
@@ -192,13 +197,13 @@ class TrainPipeline:
         if self._closed:
             raise RuntimeError("TrainPipeline.step() after close()")
         # the inputs were produced on the caller's stream (an H2D copy, a noise kernel, a slice of a pool): order the
-        # extraction stream after it, and tell the caching allocator that the tensors are in use there so that a
-        # temporary handed to step() is not recycled while the MFCC kernels still read it
+        # extraction stream after it.  Below, the caller's stream is in turn ordered after this step's extraction, so a
+        # temporary handed to step() and freed right after it is not recycled (the caching allocator re-issues a block on
+        # the stream it was allocated on) while the MFCC kernels still read it.  (Not record_stream(): the allocator would
+        # then record events on the CU-masked stream whenever such a block is freed -- also after close() destroyed it.)
         caller = torch.cuda.current_stream(self.dev)
-        self.mfcc_stream.wait_stream(caller)
-        for t in (waves, y_onehot, features):
-            if t is not None:
-                t.record_stream(self.mfcc_stream)
+        if self.sync_inputs:
+            self.mfcc_stream.wait_stream(caller)
         with torch.cuda.stream(self.mfcc_stream):
             if self._ev_free[b] is not None:
                 self.mfcc_stream.wait_event(self._ev_free[b])  # the step that last read this buffer is done
@@ -211,6 +216,8 @@ class TrainPipeline:
                     self.ex(waves, self.L, self.mean, self.scale, out=self._feats2[b][:bsz])
             self._labels2[b][:bsz].copy_(y_onehot)
             self._ev_feat[b].record(self.mfcc_stream)
+        if self.sync_inputs:
+            caller.wait_event(self._ev_feat[b])
         with torch.cuda.stream(self.stream):
             self._warm_start()
             self.stream.wait_event(self._ev_feat[b])

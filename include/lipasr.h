@@ -337,7 +337,9 @@ int lipasr_mfcc_profile_begin(lipasr_handle_t h, int max_calls);
 int lipasr_mfcc_profile_end(lipasr_handle_t h, float* avg_ms3, int* n_calls);
 int lipasr_mfcc_plan_profile_begin(lipasr_mfcc_t p, int max_calls);
 int lipasr_mfcc_plan_profile_end(lipasr_mfcc_t p, float* avg_ms3, int* n_calls);
-/* knobs of one plan: keys as lipasr_debug_set */
+/* knobs of one plan: keys 0 and 1 as lipasr_debug_set; key 2: value != 0 makes the plan run the fused resample -> STFT
+ * kernel for every batch (1.9x the algorithmic HBM bytes instead of 4.5x, but about 1.5x the time of the three-kernel path
+ * on a whole MI355X: DESIGN.md section 3); by default the fused kernel runs only where it is needed (int16 input, n_valid). */
 int lipasr_mfcc_plan_set(lipasr_mfcc_t p, int key, int value);
 
 /* A12 audio-domain noise on device, Philox RNG (attacks.py:73-86, 145-183, 222-245), in place on

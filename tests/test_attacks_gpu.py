@@ -162,7 +162,10 @@ def test_file_level_black_box_helpers(cuda, tmp_path):
         files.append(str(path))
     clean = black_box_attack_on_audio(files[0], 44)
     assert clean.shape == (20, 44) and clean.dtype == np.float32
-    np.testing.assert_allclose(clean, extract_features(files[0], 44), rtol=0, atol=1e-5)  # sigma = p = alpha = 0: no noise branch
+    # sigma = p = alpha = 0: no noise branch.  Not bit-equal: extract_features runs the fused resample -> STFT kernel, the
+    # attack path resamples, (adds noise) and runs the STFT kernel on the 22 kHz signal; their FFT twiddles differ in the
+    # last bit (table values vs products of table values): ~5e-5 in MFCC units, 400x inside the 2e-2 parity tolerance
+    np.testing.assert_allclose(clean, extract_features(files[0], 44), rtol=0, atol=1e-3)
     ds = black_box_attack_on_audio_dataset(files, 0.02, 0, 0, seed=5)
     one = black_box_attack_on_audio(files[0], 44, sigma=0.02, seed=5)
     np.testing.assert_allclose(one.reshape(-1), ds[0], rtol=0, atol=1e-4)

@@ -138,16 +138,37 @@ def test_fused_kernel_equals_three_kernel_path(cuda):
 
     waves, _ = synth_clips(40, seed=11)
     ex = MfccExtractor(16000, 16000, 64)
-    assert ex.fused
-    a = ex(dev(waves)).cpu().numpy()
-    ex.set(0, 128)
-    b = ex(dev(waves)).cpu().numpy()
+    assert ex.fused  # the plan CAN fuse; by default it does so only for int16 / ragged input
+    b = ex(dev(waves)).cpu().numpy()  # default: three-kernel path, dual-FFT STFT kernel
+    ex.set(0, 64)  # ... with the round-2 one-pair-per-workgroup STFT kernel
+    b2 = ex(dev(waves)).cpu().numpy()
     ex.set(0, 0)
+    ex.set(2, 1)  # the fused kernel for every batch
+    a = ex(dev(waves)).cpu().numpy()
     c = ex(dev(waves)).cpu().numpy()
     assert np.array_equal(a, c)  # deterministic
     assert np.abs(a - b).max() < 2e-3, np.abs(a - b).max()
+    assert np.abs(b - b2).max() < 2e-3, np.abs(b - b2).max()  # dual-FFT kernel (four frames per workgroup) vs the pair kernel
     ref = M.compute_mfcc_batch(waves[:8])
-    assert np.abs(a[:8] - ref).max() < ATOL and np.abs(b[:8] - ref).max() < ATOL
+    assert max(np.abs(x[:8] - ref).max() for x in (a, b, b2)) < ATOL
+
+
+@pytest.mark.parametrize("n", [22050, 9000, 1500, 23000, 2])
+def test_dual_fft_kernel_frame_counts(cuda, n):
+    """stft_mel2_kernel handles four frames per workgroup: frame counts 44 (multiple of 4), 18 and 45 (partial last quad,
+    incl. a lone fifth frame), 3 (every frame reflects) and 1, on 22 050 Hz input (no resampler in the way)."""
+    from lipasr.extract_features_construct_dataset import MfccExtractor
+
+    rng = np.random.default_rng(n)
+    w = (0.2 * rng.standard_normal((3, n))).astype(np.float32)
+    ex = MfccExtractor(22050, n, 4)
+    L = 1 + n // 512
+    got = ex(dev(w), L).cpu().numpy()
+    ref = M.compute_mfcc_batch(w, sr_in=22050, utterance_length=L)
+    assert np.abs(got - ref).max() < ATOL, np.abs(got - ref).max()
+    ex.set(0, 64)
+    old = ex(dev(w), L).cpu().numpy()
+    assert np.abs(got - old).max() < 2e-3
 
 
 @pytest.mark.parametrize("sr_in,n", [(16000, 16000), (8000, 8000), (16000, 24000), (16000, 5003)])
@@ -159,6 +180,7 @@ def test_fused_kernel_other_rates_and_lengths(cuda, sr_in, n):
     w = (0.3 * np.sin(2 * np.pi * (300 + 200 * np.arange(5)[:, None]) * t) + 0.05 * rng.standard_normal((5, n))).astype(np.float32)
     ex = MfccExtractor(sr_in, n, 8)
     assert ex.fused
+    ex.set(2, 1)
     got = ex(dev(w), 50).cpu().numpy()
     ref = M.compute_mfcc_batch(w, sr_in=sr_in, utterance_length=50)
     assert np.abs(got - ref).max() < ATOL, np.abs(got - ref).max()
@@ -173,6 +195,7 @@ def test_int16_pcm_input_is_bit_identical(cuda):
     waves, _ = synth_clips(19, seed=3)
     pcm = np.clip(np.round(waves * 32768.0), -32768, 32767).astype(np.int16)
     ex = MfccExtractor(16000, 16000, 32)
+    ex.set(2, 1)  # float32 batches through the fused kernel as well (int16 always takes it)
     a = ex(torch.as_tensor(pcm).cuda())
     b = ex(dev(pcm.astype(np.float32) / 32768.0))
     assert torch.equal(a, b)
@@ -184,9 +207,11 @@ def test_int16_pcm_input_is_bit_identical(cuda):
 
     odd = pcm[:, :15999].copy()
     exo = MfccExtractor(16000, 15999, 32)
+    exo.set(2, 1)
     assert torch.equal(exo(torch.as_tensor(odd).cuda()), exo(dev(odd.astype(np.float32) / 32768.0)))
     h = N.get_handle(0)
     N.check(N.lib.lipasr_mfcc_plan(h.h, 16000, 16000, 32))
+    N.check(N.lib.lipasr_debug_set(h.h, 2, 1))
     out = torch.empty(19, 880, device="cuda")
     N.check(N.lib.lipasr_mfcc_i16(h.h, N.ptr(torch.as_tensor(pcm).cuda()), None, 19, 44, None, None, N.ptr(out), N.stream_ptr()))
     assert torch.equal(out, a)
@@ -213,6 +238,7 @@ def test_ragged_batch_equals_per_clip_launches(cuda):
     got_aff = ex(dev(padded), 44, sc_mean, sc_scale, n_valid=torch.as_tensor(lens).cuda())
     for i, n in enumerate(lens):
         one = MfccExtractor(16000, int(n), 1)
+        one.set(2, 1)  # the same (fused) kernel as the ragged launch: bit-identical results are the claim
         alone = one(dev(waves[i:i + 1, :n]))
         assert torch.equal(got[i:i + 1], alone), (i, n, float((got[i:i + 1] - alone).abs().max()))
         assert torch.equal(got_aff[i:i + 1], one(dev(waves[i:i + 1, :n]), 44, sc_mean, sc_scale)), (i, n)
@@ -226,9 +252,11 @@ def test_ragged_batch_equals_per_clip_launches(cuda):
     a = mfcc(pcm, 16000, n_valid=lens)
     b = mfcc(pcm.astype(np.float32) / 32768.0, 16000, n_valid=lens)
     assert torch.equal(a, b)
-    # zero-length rows: no frame at all -> the zero columns of fix_frames
-    z = ex(dev(padded[:2]), n_valid=torch.as_tensor(np.array([0, 1], np.int32)).cuda())
-    assert torch.count_nonzero(z) == 0
+    # a zero-length row has no frame at all -> the zero columns of fix_frames; one sample resamples to ceil(1.378) = 2
+    # samples = one frame, zero columns after it
+    z = ex(dev(padded[:2]), n_valid=torch.as_tensor(np.array([0, 1], np.int32)).cuda()).cpu().numpy().reshape(2, 20, 44)
+    assert np.count_nonzero(z[0]) == 0
+    assert np.isfinite(z[1]).all() and np.count_nonzero(z[1, :, 1:]) == 0 and z[1, 0, 0] < -100.0
 
 
 def test_ragged_and_int16_need_the_fused_path(cuda):
