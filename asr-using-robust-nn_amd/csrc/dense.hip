@@ -605,6 +605,7 @@ static int launch_gemm_group_tn(const GemmArgs* gs, int n, hipStream_t st) {
 }
 
 static int g_gemm_mode = 0;  // 0 auto, 1 split-K kernel only, 2 LDS kernel wherever it is legal (profiling knob)
+static int g_split_dw0 = 0;  // lipasr_debug_gemm_mode bit 2: the first layer's weight gradient as its own launch
 
 static bool use_lds_gemm(int M, int N, int K) {
   if (g_gemm_mode == 1) return false;
@@ -983,7 +984,8 @@ using namespace lipasr;
 extern "C" {
 
 int lipasr_debug_gemm_mode(int mode) {
-  g_gemm_mode = mode;
+  g_gemm_mode = mode & 3;
+  g_split_dw0 = (mode >> 2) & 1;
   return LIPASR_OK;
 }
 
@@ -1205,9 +1207,11 @@ static int backward_infer(lipasr_mlp* m, const float* params, const float* bnsta
 
 extern "C" {
 
-int lipasr_mlp_train_fwd_bwd(lipasr_mlp_t m, const float* params, float* bnstate, const float* x, const float* y_onehot,
-                             int batch, float inv_batch, const lipasr_dropout_cfg* dropout, float* grads,
-                             float* loss_rows, float* correct_rows, float* probs, lipasr_stream_t stream) {
+// dw_mode 0: every weight gradient from ONE grouped launch; 1: the first layer's [dW; db] as its own launch after the
+// grouped launch of the others (LDS-tiled 64x64 kernel when legal); 2: the first layer's left out (lipasr_mlp_train_dw0)
+static int train_fwd_bwd_impl(lipasr_mlp_t m, const float* params, float* bnstate, const float* x, const float* y_onehot,
+                              int batch, float inv_batch, const lipasr_dropout_cfg* dropout, float* grads,
+                              float* loss_rows, float* correct_rows, float* probs, lipasr_stream_t stream, int dw_mode) {
   int rc = check_batch("lipasr_mlp_train_fwd_bwd", m, batch);
   if (rc != LIPASR_OK) return rc;
   LP_CHECK_ARG(params && x && y_onehot && grads, "lipasr_mlp_train_fwd_bwd: null argument");
@@ -1314,7 +1318,45 @@ int lipasr_mlp_train_fwd_bwd(lipasr_mlp_t m, const float* params, float* bnstate
     gw[l].extra_out = grads + L.offb;
     gw[l].bf16 = m->compute_bf16;
   }
-  return launch_gemm_group_tn(gw, Lc, st);
+  if (dw_mode == 0 || Lc == 1) return launch_gemm_group_tn(gw, Lc, st);
+  rc = launch_gemm_group_tn(gw + 1, Lc - 1, st);
+  if (rc != LIPASR_OK || dw_mode == 2) return rc;
+  return launch_gemm(1, 1, gw[0], st);
+}
+
+int lipasr_mlp_train_fwd_bwd(lipasr_mlp_t m, const float* params, float* bnstate, const float* x, const float* y_onehot,
+                             int batch, float inv_batch, const lipasr_dropout_cfg* dropout, float* grads,
+                             float* loss_rows, float* correct_rows, float* probs, lipasr_stream_t stream) {
+  return train_fwd_bwd_impl(m, params, bnstate, x, y_onehot, batch, inv_batch, dropout, grads, loss_rows, correct_rows, probs,
+                            stream, g_split_dw0 ? 1 : 0);
+}
+
+int lipasr_mlp_train_fwd_bwd_head(lipasr_mlp_t m, const float* params, float* bnstate, const float* x, const float* y_onehot,
+                                  int batch, float inv_batch, const lipasr_dropout_cfg* dropout, float* grads,
+                                  float* loss_rows, float* correct_rows, float* probs, lipasr_stream_t stream) {
+  return train_fwd_bwd_impl(m, params, bnstate, x, y_onehot, batch, inv_batch, dropout, grads, loss_rows, correct_rows, probs,
+                            stream, 2);
+}
+
+int lipasr_mlp_train_dw0(lipasr_mlp_t m, const float* x, int batch, float* grads, lipasr_stream_t stream) {
+  int rc = check_batch("lipasr_mlp_train_dw0", m, batch);
+  if (rc != LIPASR_OK) return rc;
+  LP_CHECK_ARG(x && grads, "lipasr_mlp_train_dw0: null argument");
+  if (m->n_layers == 1) return LIPASR_OK;  // a one-layer plan's head already holds every gradient
+  const MlpLayer& L = m->L[0];
+  GemmArgs g = gemm_args(x, L.n_in, m->ws + L.offDz, L.n_out, grads + L.offW, L.n_out, L.n_in + 1, L.n_out, batch, EPI_STORE);
+  g.ones_row = 1;
+  g.extra_out = grads + L.offb;
+  g.bf16 = m->compute_bf16;
+  return launch_gemm(1, 1, g, S(stream));
+}
+
+int lipasr_mlp_grad_split(lipasr_mlp_t m, size_t* late_floats) {
+  LP_CHECK_ARG(m && late_floats, "lipasr_mlp_grad_split: null argument");
+  // [W0 | b0] come from lipasr_mlp_train_dw0; what follows in the flat layout (gamma0, beta0, layers 1..) is final after the head
+  const MlpLayer& L = m->L[0];
+  *late_floats = (m->n_layers == 1) ? 0 : (L.bn ? L.offg : m->L[1].offW);
+  return LIPASR_OK;
 }
 
 int lipasr_mlp_predict(lipasr_mlp_t m, const float* params, const float* bnstate, const float* x, int batch,

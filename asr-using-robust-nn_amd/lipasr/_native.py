@@ -77,6 +77,9 @@ PROTOTYPES = {
     "lipasr_mlp_sizes": (i32, [c_h, C.POINTER(sz), C.POINTER(sz)]),
     "lipasr_mlp_segment": (i32, [c_h, i32, i32, C.POINTER(sz), C.POINTER(sz)]),
     "lipasr_mlp_train_fwd_bwd": (i32, [c_h, c_f, c_f, c_f, c_f, i32, f32, C.POINTER(DropoutCfg), c_f, c_f, c_f, c_f, c_s]),
+    "lipasr_mlp_train_fwd_bwd_head": (i32, [c_h, c_f, c_f, c_f, c_f, i32, f32, C.POINTER(DropoutCfg), c_f, c_f, c_f, c_f, c_s]),
+    "lipasr_mlp_train_dw0": (i32, [c_h, c_f, i32, c_f, c_s]),
+    "lipasr_mlp_grad_split": (i32, [c_h, C.POINTER(sz)]),
     "lipasr_mlp_adam_nonneg": (i32, [c_h, c_f, c_f, c_f, c_f, c_f, f32, f32, f32, f32, f32, c_s]),
     "lipasr_mlp_project_product": (i32, [c_h, c_f, f32, PI, i32, c_f, c_s]),
     "lipasr_mlp_adam_project_product": (i32, [c_h, c_f, c_f, c_f, c_f, c_f, f32, f32, f32, f32, f32, f32, PI, i32, c_f, c_s]),
@@ -116,6 +119,10 @@ for _name, (_res, _args) in PROTOTYPES.items():
     _fn = getattr(lib, _name)  # AttributeError here = header and library out of sync
     _fn.restype = _res
     _fn.argtypes = _args
+
+
+if os.environ.get("LIPASR_GEMM_MODE"):  # A/B timing knob (lipasr_debug_gemm_mode): never a different backend
+    lib.lipasr_debug_gemm_mode(int(os.environ["LIPASR_GEMM_MODE"]))
 
 
 def last_error() -> str:

@@ -340,6 +340,7 @@ class Model:
         self._compiled = False
         self._dp = None  # lipasr.parallel.DataParallel, optional
         self._dropout_seed = 0x5EED0000 + seed
+        self._replica_rank = 0  # data parallel: folded into the dropout key, so that every rank draws its own masks
         self._device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self._build()
 
@@ -477,20 +478,34 @@ class Model:
             cfg.masks = C.cast(self._mask_ptrs, N.PV)
         elif enable and any(b["drop"] for b in self._blocks):
             cfg.mode = 1
-            cfg.seed = self._dropout_seed
+            # Philox key = seed (+ rank): the counter is (local element, layer, step), which is the same on every rank
+            cfg.seed = (self._dropout_seed + 0x9E3779B97F4A7C15 * self._replica_rank) & 0xFFFFFFFFFFFFFFFF
             cfg.step_dev = self._step.data_ptr()
         else:
             cfg.mode = 0
         return cfg
 
-    def train_fwd_bwd(self, xb, yb, inv_batch=None, masks=None, dropout=True, probs=None):
-        """Enqueue forward + loss + backward for one batch (device tensors); grads land in self._grads."""
+    def train_fwd_bwd(self, xb, yb, inv_batch=None, masks=None, dropout=True, probs=None, defer_dw0=False):
+        """Enqueue forward + loss + backward for one batch (device tensors); grads land in self._grads.
+        defer_dw0 (data parallel): everything except the first layer's [dW | db] -- ``self._grads[self.late_floats:]`` is
+        final when this call's kernels are, ``train_dw0(xb)`` then fills ``self._grads[:self.late_floats]``."""
         bsz = xb.shape[0]
         cfg = self._dropout_cfg(masks, dropout)
         inv = 1.0 / bsz if inv_batch is None else inv_batch
-        N.check(N.lib.lipasr_mlp_train_fwd_bwd(self._plan, N.ptr(self._params), N.ptr(self._bnstate), N.ptr(xb), N.ptr(yb), bsz, inv,
-                                               C.byref(cfg), N.ptr(self._grads), N.ptr(self._loss_rows), N.ptr(self._correct_rows),
-                                               N.ptr(probs), N.stream_ptr()))
+        fn = N.lib.lipasr_mlp_train_fwd_bwd_head if defer_dw0 else N.lib.lipasr_mlp_train_fwd_bwd
+        N.check(fn(self._plan, N.ptr(self._params), N.ptr(self._bnstate), N.ptr(xb), N.ptr(yb), bsz, inv,
+                   C.byref(cfg), N.ptr(self._grads), N.ptr(self._loss_rows), N.ptr(self._correct_rows),
+                   N.ptr(probs), N.stream_ptr()))
+
+    def train_dw0(self, xb):
+        N.check(N.lib.lipasr_mlp_train_dw0(self._plan, N.ptr(xb), xb.shape[0], N.ptr(self._grads), N.stream_ptr()))
+
+    @property
+    def late_floats(self):
+        """Length of the leading part of the flat gradient ([dW_0 | db_0]) that ``train_dw0`` produces."""
+        n = N.sz()
+        N.check(N.lib.lipasr_mlp_grad_split(self._plan, C.byref(n)))
+        return int(n.value)
 
     def apply_adam(self, grad_scale=1.0):
         lr, b1, b2, eps = self._adam

@@ -3,7 +3,10 @@ into contiguous per-rank slices, ONE sum all-reduce per step over the flat fp32 
 (torch.distributed backend "nccl" = RCCL over xGMI on ROCm; "gloo" on CPU for tests), the 1/global
 batch factor folded into the loss gradient, then Adam + NonNeg + the Lipschitz projection run
 redundantly and deterministically on every replica (no second exchange; the kernels use no float
-atomics, so replicas stay bit-identical).  BatchNorm statistics are per replica.
+atomics, so replicas stay bit-identical).  The exchange goes in two buckets so that 44 % of it overlaps the
+first layer's weight-gradient GEMM (train_step_overlapped / TrainPipeline).  BatchNorm statistics are per
+replica (tests/test_dp_gloo.py and tests/test_dp_gpu.py check accuracy parity with the single-process run);
+every rank draws its own dropout masks (the rank is folded into the Philox key).
 
 The reference has no counterpart (single process, train_constraints.py:91-105).
 
@@ -40,6 +43,11 @@ def shard_bounds(n, rank, world):
     base, rem = divmod(n, world)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+class _Done:
+    def wait(self):
+        return True
 
 
 class DataParallel:
@@ -81,13 +89,45 @@ class DataParallel:
                 dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         return flat
 
+    def allreduce_async(self, flat):
+        """Start an in-place SUM over ``flat`` (a bucket of the gradient buffer) ordered after the CURRENT stream's work;
+        returns a handle whose ``wait()`` orders the current stream after the reduction.  With RCCL the reduction runs on
+        the communicator's own stream, beside whatever the caller enqueues next (the first layer's weight-gradient GEMM);
+        the host-staged gloo rehearsal and world size 1 complete in place and return a no-op handle."""
+        if self.world == 1:
+            return _Done()
+        if self._host_staged(flat) or dist.get_backend(self.group) != "nccl":
+            self.allreduce_grads(flat)
+            return _Done()
+        return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
     def train_step(self, replica, xb, yb, global_batch=None, **kw):
         """xb, yb: this rank's shard.  Per-replica gradients carry 1/global_batch, so their SUM is the
         gradient of the mean loss over the global batch."""
         if global_batch is None:
             global_batch = self.global_count(xb.shape[0])
+        if hasattr(replica, "_replica_rank"):
+            replica._replica_rank = self.rank  # every rank its own dropout masks
         replica.train_fwd_bwd(xb, yb, inv_batch=1.0 / float(global_batch), **kw)
         self.allreduce_grads(replica.grads)
+        replica.apply_adam()
+
+    def train_step_overlapped(self, replica, xb, yb, global_batch=None, **kw):
+        """The same step with the gradient exchange in two buckets (what TrainPipeline captures as three HIP graphs):
+        everything but the first layer's [dW | db] is reduced while that GEMM -- 56 % of the bytes, and the last thing a
+        backward pass can start -- still runs.  The replica needs ``train_fwd_bwd(..., defer_dw0=True)``, ``train_dw0(x)``
+        and ``late_floats``."""
+        if global_batch is None:
+            global_batch = self.global_count(xb.shape[0])
+        if hasattr(replica, "_replica_rank"):
+            replica._replica_rank = self.rank
+        replica.train_fwd_bwd(xb, yb, inv_batch=1.0 / float(global_batch), defer_dw0=True, **kw)
+        late = replica.late_floats
+        ha = self.allreduce_async(replica.grads[late:])
+        replica.train_dw0(xb)
+        hb = self.allreduce_async(replica.grads[:late])
+        ha.wait()
+        hb.wait()
         replica.apply_adam()
 
     def global_count(self, local_n):

@@ -26,7 +26,7 @@ from .parallel import DataParallel
 
 class TrainPipeline:
     def __init__(self, model, batch, sr_in=16000, n_samp=16000, utterance_length=44, rho=0.1, constraint="product",
-                 affine=None, pgd=None, dp=None, use_graph=True, per_layer_iters=4, extractor=None, mfcc_cus="auto", sync_inputs=True):
+                 affine=None, pgd=None, dp=None, use_graph=True, per_layer_iters=4, extractor=None, mfcc_cus="auto", sync_inputs=True, overlap_buckets=False):
         """constraint: 'product' (simple_norm_constraint, all layers), 'per_layer' (norm_constraint) or None.
         affine: (mean, scale) float64 device tensors [20*utterance_length] or None.
         pgd: dict(eps=, eps_step=, max_iter=) for adversarial training on the standardised features.
@@ -39,6 +39,12 @@ class TrainPipeline:
         were just produced on the caller's stream or are temporaries; a loop over a resident pool that was filled and
         synchronised beforehand (bench.py) may pass False."""
         self.sync_inputs = bool(sync_inputs)
+        # Data parallel, gradient exchange.  False: two HIP graphs around ONE all-reduce of the whole flat buffer.  True:
+        # three graphs around two buckets, everything but [dW_0 | db_0] (44 % of the bytes) reduced beside the dW_0 GEMM.
+        # Measured on one MI355X with a one-rank RCCL group (identity collectives, scratch/nccl_one_rank.py): the extra
+        # graph boundary and the second collective's stream hand-offs cost +57 us per step against +14 us for the
+        # one-collective schedule, more than the ~36 us of wire time the overlap can hide at this message size.
+        self.overlap_buckets = bool(overlap_buckets)
         self.model, self.batch, self.L = model, int(batch), int(utterance_length)
         self.dev = model._device
         self.h = N.get_handle(self.dev.index)
@@ -46,6 +52,8 @@ class TrainPipeline:
         self._custom_ex = extractor is not None
         self.rho, self.constraint, self.pgd = float(rho), constraint, pgd
         self.dp = dp if dp is not None else DataParallel()
+        model._replica_rank = self.dp.rank  # every rank draws its own dropout masks
+        self._late = model.late_floats      # [dW_0 | db_0]: the gradient bucket that is ready last
         self.use_graph = use_graph
         self.per_layer_iters = per_layer_iters
         self.mean, self.scale = affine if affine is not None else (None, None)
@@ -126,7 +134,7 @@ class TrainPipeline:
         return torch.cuda.ExternalStream(st.value, device=self.dev)
 
     # ---- pieces (all enqueue on the current stream)
-    def _attack_and_train(self, bsz, b, global_batch):
+    def _attack_and_train(self, bsz, b, global_batch, defer_dw0=False):
         m = self.model
         x = self._feats2[b][:bsz]
         y = self._labels2[b][:bsz]
@@ -137,7 +145,21 @@ class TrainPipeline:
                 N.check(N.lib.lipasr_mlp_attack_step(m._plan, N.ptr(m._params), N.ptr(m._bnstate), N.ptr(xa), N.ptr(x), N.ptr(y), bsz,
                                                      float(self.pgd.get("eps_step", 0.1)), float(self.pgd["eps"]), N.stream_ptr()))
             x = xa
-        m.train_fwd_bwd(x, y, inv_batch=1.0 / float(global_batch))
+        m.train_fwd_bwd(x, y, inv_batch=1.0 / float(global_batch), defer_dw0=defer_dw0)
+
+    def _dw0(self, bsz, b):
+        self.model.train_dw0((self.x_adv if self.pgd else self._feats2[b])[:bsz])
+
+    def _reduce_and_update_eager(self, bsz, b):
+        """world > 1, no graphs: head -> [bucket A reduces] || dW_0 -> bucket B -> Adam + projection."""
+        m = self.model
+        late = self._late
+        ha = self.dp.allreduce_async(m._grads[late:])
+        self._dw0(bsz, b)
+        hb = self.dp.allreduce_async(m._grads[:late])
+        ha.wait()
+        hb.wait()
+        self._update()
 
     def _update(self):
         m = self.model
@@ -227,19 +249,39 @@ class TrainPipeline:
                 self._prof_i += 1
                 prof[0].record(self.stream)
             if not self.use_graph:
-                self._attack_and_train(bsz, b, gb)
-                self.dp.allreduce_grads(self.model._grads)
-                self._update()
+                if self.dp.world == 1:
+                    self._attack_and_train(bsz, b, gb)
+                    self._update()
+                elif self.overlap_buckets:
+                    self._attack_and_train(bsz, b, gb, defer_dw0=True)
+                    self._reduce_and_update_eager(bsz, b)
+                else:
+                    self._attack_and_train(bsz, b, gb)
+                    self.dp.allreduce_grads(self.model._grads)
+                    self._update()
             else:
                 g = self._graphs.get((bsz, b, gb))
                 if g is None:
                     if self.dp.world == 1:
                         g = (self._capture(lambda: (self._attack_and_train(bsz, b, gb), self._update())),)
+                    elif self.overlap_buckets:
+                        # three graphs around the two gradient buckets (reduce what is ready while the backward
+                        # pass still computes): [attack + fwd/bwd without dW_0] | [dW_0] | [Adam + projection]
+                        g = (self._capture(self._attack_and_train, bsz, b, gb, True), self._capture(self._dw0, bsz, b),
+                             self._capture(self._update))
                     else:
                         g = (self._capture(self._attack_and_train, bsz, b, gb), self._capture(self._update))
                     self._graphs[(bsz, b, gb)] = g
                 N.check(N.lib.lipasr_graph_launch(self.h.h, g[0], N.stream_ptr()))
-                if len(g) == 2:
+                if len(g) == 3:
+                    late = self._late
+                    ha = self.dp.allreduce_async(self.model._grads[late:])   # 44 % of the bytes, beside the dW_0 GEMM
+                    N.check(N.lib.lipasr_graph_launch(self.h.h, g[1], N.stream_ptr()))
+                    hb = self.dp.allreduce_async(self.model._grads[:late])
+                    ha.wait()
+                    hb.wait()
+                    N.check(N.lib.lipasr_graph_launch(self.h.h, g[2], N.stream_ptr()))
+                elif len(g) == 2:
                     self.dp.allreduce_grads(self.model._grads)
                     N.check(N.lib.lipasr_graph_launch(self.h.h, g[1], N.stream_ptr()))
             if prof is not None:

@@ -201,6 +201,18 @@ int lipasr_mlp_train_fwd_bwd(lipasr_mlp_t m, const float* params, float* bnstate
                              const lipasr_dropout_cfg* dropout, float* grads, float* loss_rows,
                              float* correct_rows, float* probs, lipasr_stream_t stream);
 
+/* Data-parallel form of lipasr_mlp_train_fwd_bwd (no reference counterpart: train_constraints.py:91-105 is one
+ * process): the same kernels in two calls, so that the gradient all-reduce of everything but the first layer's kernel
+ * runs while that kernel's gradient -- 56 % of the bytes and the last thing a backward pass can start -- is still being
+ * computed.  _head: forward, loss, the whole dX chain and every gradient except [dW_0 | db_0]; _dw0: those two.
+ * lipasr_mlp_grad_split: the first `late_floats` floats of `grads` belong to _dw0, the rest is final after _head. */
+int lipasr_mlp_train_fwd_bwd_head(lipasr_mlp_t m, const float* params, float* bnstate, const float* x,
+                                  const float* y_onehot, int batch, float inv_batch,
+                                  const lipasr_dropout_cfg* dropout, float* grads, float* loss_rows,
+                                  float* correct_rows, float* probs, lipasr_stream_t stream);
+int lipasr_mlp_train_dw0(lipasr_mlp_t m, const float* x, int batch, float* grads, lipasr_stream_t stream);
+int lipasr_mlp_grad_split(lipasr_mlp_t m, size_t* late_floats);
+
 /* K5: Keras Adam (optimizer='adam', train_constraints.py:94) then NonNeg (:67-85) in one launch
  * over the flat buffers: g' = g*grad_scale; m = b1 m + (1-b1) g'; v = b2 v + (1-b2) g'^2;
  * w -= lr*sqrt(1-b2^t)/(1-b1^t) * m / (sqrt(v) + eps); then w = w*[w>=0] on NonNeg kernels.
@@ -357,8 +369,9 @@ int lipasr_add_noise_f32(lipasr_handle_t h, float* y, int batch, int n, int mode
  * pipeline that runs the MFCC on a CU-masked stream sets it to the size of the mask).  Kept in the handle. */
 int lipasr_debug_set(lipasr_handle_t h, int key, int value);
 
-/* Profiling knob: GEMM kernel choice. 0 = automatic, 1 = split-K register kernel only, 2 = LDS-tiled kernel
- * wherever it is legal. */
+/* Profiling knob: GEMM kernel choice. bits 0-1: 0 = automatic, 1 = split-K register kernel only, 2 = LDS-tiled kernel
+ * wherever it is legal.  bit 2 (4): lipasr_mlp_train_fwd_bwd launches the first layer's weight gradient on its own
+ * (as the data-parallel head / dw0 pair does) instead of inside the grouped launch. */
 int lipasr_debug_gemm_mode(int mode);
 
 /* Host-only (no GPU needed): copies one constant table, exactly as the kernels read it, into `out`
