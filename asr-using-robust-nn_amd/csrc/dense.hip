@@ -759,6 +759,7 @@ struct BnFwdArgs {
   const float* a;  // [B][N] post-ReLU
   float* h;        // [B][N] out
   int B, N, has_bn, n_tiles;
+  int Bstat;          // rows the statistics are taken over (= B; synchronized BatchNorm: the global batch)
   const float* part;  // [2][n_tiles][N]: sums of a and a^2 per row tile
   const float* gamma;
   const float* beta;
@@ -797,8 +798,8 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(BnFwdArgs p) {
       float var[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const double m = s1[e] / (double)p.B;
-        double v = s2[e] / (double)p.B - m * m;
+        const double m = s1[e] / (double)p.Bstat;
+        double v = s2[e] / (double)p.Bstat - m * m;
         v = v > 0.0 ? v : 0.0;
         mean[e] = (float)m;
         var[e] = (float)v;
@@ -845,6 +846,8 @@ struct BnBwdArgs {
   const float* a;   // [B][N] post-ReLU
   float* dz;        // [B][N] gradient w.r.t. the pre-activation
   int B, N, n_tiles;
+  int Bstat;          // rows the statistics were taken over (= B; synchronized BatchNorm: the global batch)
+  float grad_scale;   // 1, or 1 / world when the partial sums were all-reduced (the gradient all-reduce sums them again)
   const float* part;  // [2][n_tiles][N]: sums of g and g * xhat per row tile
   const float* gamma;
   const float* save_mean;
@@ -884,10 +887,13 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(BnBwdArgs p) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) { dbt[e] = (float)s1[e]; dg[e] = (float)s2[e]; }
   if (blockIdx.y == 0 && rl == 0) {
-    st4(p.dbeta, 0, c, dbt);
-    st4(p.dgamma, 0, c, dg);
+    float ob[4], og[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { ob[e] = dbt[e] * p.grad_scale; og[e] = dg[e] * p.grad_scale; }
+    st4(p.dbeta, 0, c, ob);
+    st4(p.dgamma, 0, c, og);
   }
-  const float invB = 1.0f / (float)p.B;
+  const float invB = 1.0f / (float)p.Bstat;
 #pragma unroll
   for (int i = 0; i < kApplyRows / 8; ++i) {
     const int b = blockIdx.y * kApplyRows + rl + 8 * i;
@@ -1209,9 +1215,22 @@ extern "C" {
 
 // dw_mode 0: every weight gradient from ONE grouped launch; 1: the first layer's [dW; db] as its own launch after the
 // grouped launch of the others (LDS-tiled 64x64 kernel when legal); 2: the first layer's left out (lipasr_mlp_train_dw0)
+// Segments (synchronized BatchNorm under data parallelism): the launch sequence is cut after every GEMM whose epilogue
+// leaves BatchNorm column partial sums (forward: sums of a, a^2; backward: sums of g, g xhat), i.e. right before the
+// apply kernel that consumes them.  seg < 0 runs everything; otherwise only the launches of segment `seg`, and the caller
+// SUM-all-reduces the partials (segment_exchange_floats) before it runs the next one.  part_ext: caller-owned partials
+// buffer (a torch tensor the caller can hand to its collective), stat_batch: rows the statistics cover (global batch).
+struct SegArgs {
+  int seg = -1;
+  float* part_ext = nullptr;
+  int stat_batch = 0;
+  float grad_scale = 1.0f;
+};
+
 static int train_fwd_bwd_impl(lipasr_mlp_t m, const float* params, float* bnstate, const float* x, const float* y_onehot,
                               int batch, float inv_batch, const lipasr_dropout_cfg* dropout, float* grads,
-                              float* loss_rows, float* correct_rows, float* probs, lipasr_stream_t stream, int dw_mode) {
+                              float* loss_rows, float* correct_rows, float* probs, lipasr_stream_t stream, int dw_mode,
+                              const SegArgs& sa = SegArgs()) {
   int rc = check_batch("lipasr_mlp_train_fwd_bwd", m, batch);
   if (rc != LIPASR_OK) return rc;
   LP_CHECK_ARG(params && x && y_onehot && grads, "lipasr_mlp_train_fwd_bwd: null argument");
@@ -1222,8 +1241,11 @@ static int train_fwd_bwd_impl(lipasr_mlp_t m, const float* params, float* bnstat
   const int Lc = m->n_layers;
   const int C = m->L[Lc - 1].n_out;
   float* ws = m->ws;
-  float* part = ws + m->offPart;
+  float* part = sa.part_ext ? sa.part_ext : (ws + m->offPart);
   const dim3 apply_block(256);
+  const int bstat = sa.stat_batch > 0 ? sa.stat_batch : batch;
+  int cur = 0;  // current segment
+#define LP_ON (sa.seg < 0 || sa.seg == cur)
 
   // ---- forward (training mode): GEMM (+bias, ReLU, column partials) -> BatchNorm/dropout apply
   const float* hin = x;
@@ -1245,12 +1267,16 @@ static int train_fwd_bwd_impl(lipasr_mlp_t m, const float* params, float* bnstat
       g.correct_rows = correct_rows;
     }
     g.bf16 = m->compute_bf16;
-    rc = launch_gemm(0, 1, g, st);
-    if (rc != LIPASR_OK) return rc;
-    if (!last && L.offH != L.offA) {
+    if (LP_ON) {
+      rc = launch_gemm(0, 1, g, st);
+      if (rc != LIPASR_OK) return rc;
+    }
+    if (!last && L.bn) ++cur;  // exchange point: the partial sums of a, a^2 are complete
+    if (!last && L.offH != L.offA && LP_ON) {
       BnFwdArgs b;
       memset(&b, 0, sizeof(b));
       b.a = ws + L.offA; b.h = ws + L.offH; b.B = batch; b.N = L.n_out; b.has_bn = L.bn ? 1 : 0;
+      b.Bstat = bstat;
       b.part = part;
       b.n_tiles = stats_row_tiles(batch, L.n_out, L.n_in);
       if (L.bn) {
@@ -1262,13 +1288,11 @@ static int train_fwd_bwd_impl(lipasr_mlp_t m, const float* params, float* bnstat
       const dim3 grid((L.n_out + 127) / 128, (batch + kApplyRows - 1) / kApplyRows);
       hipLaunchKernelGGL(bn_apply_fwd_kernel, grid, apply_block, 0, st, b);
       LP_LAUNCH_CHECK();
-      hin = ws + L.offH;
-    } else {
-      hin = outp;
     }
+    hin = (!last && L.offH != L.offA) ? (ws + L.offH) : outp;
   }
   // ---- loss and gradient at the logits (already done by the last GEMM's epilogue for <= 32 classes)
-  if (C > 32) {
+  if (C > 32 && LP_ON) {
     hipLaunchKernelGGL(softmax_ce_kernel, dim3((batch + 255) / 256), dim3(256), 0, st, ws + m->offLogits, y_onehot, batch,
                        C, inv_batch, probs ? probs : (ws + m->offProb), ws + m->offDzLast, loss_rows, correct_rows,
                        (float*)nullptr);
@@ -1292,12 +1316,16 @@ static int train_fwd_bwd_impl(lipasr_mlp_t m, const float* params, float* bnstat
     gx.part = part;
     if (P.bn) gx.save_mean = ws + P.offMean;
     gx.bf16 = m->compute_bf16;
-    rc = launch_gemm(0, 0, gx, st);
-    if (rc != LIPASR_OK) return rc;
-    if (P.bn) {
+    if (LP_ON) {
+      rc = launch_gemm(0, 0, gx, st);
+      if (rc != LIPASR_OK) return rc;
+    }
+    if (P.bn) ++cur;  // exchange point: the partial sums of g, g xhat are complete
+    if (P.bn && LP_ON) {
       BnBwdArgs b;
       memset(&b, 0, sizeof(b));
       b.g = tmp; b.a = ws + P.offA; b.dz = ws + P.offDz; b.B = batch; b.N = P.n_out;
+      b.Bstat = bstat; b.grad_scale = sa.grad_scale;
       b.part = part;
       b.n_tiles = stats_row_tiles(batch, P.n_out, L.n_out);
       b.gamma = params + P.offg; b.save_mean = ws + P.offMean;
@@ -1318,6 +1346,8 @@ static int train_fwd_bwd_impl(lipasr_mlp_t m, const float* params, float* bnstat
     gw[l].extra_out = grads + L.offb;
     gw[l].bf16 = m->compute_bf16;
   }
+  if (!LP_ON) return LIPASR_OK;
+#undef LP_ON
   if (dw_mode == 0 || Lc == 1) return launch_gemm_group_tn(gw, Lc, st);
   rc = launch_gemm_group_tn(gw + 1, Lc - 1, st);
   if (rc != LIPASR_OK || dw_mode == 2) return rc;
@@ -1349,6 +1379,57 @@ int lipasr_mlp_train_dw0(lipasr_mlp_t m, const float* x, int batch, float* grads
   g.extra_out = grads + L.offb;
   g.bf16 = m->compute_bf16;
   return launch_gemm(1, 1, g, S(stream));
+}
+
+int lipasr_mlp_train_segments(lipasr_mlp_t m, int* n_segments) {
+  LP_CHECK_ARG(m && n_segments, "lipasr_mlp_train_segments: null argument");
+  int n = 1;
+  for (int l = 0; l + 1 < m->n_layers; ++l)
+    if (m->L[l].bn) n += 2;  // one exchange in the forward pass, one in the backward pass
+  *n_segments = n;
+  return LIPASR_OK;
+}
+
+// floats of the partials buffer to SUM-all-reduce after segment `seg` (0 after the last one)
+int lipasr_mlp_train_segment_exchange(lipasr_mlp_t m, int batch, int seg, size_t* floats) {
+  int rc = check_batch("lipasr_mlp_train_segment_exchange", m, batch);
+  if (rc != LIPASR_OK) return rc;
+  LP_CHECK_ARG(floats != nullptr && seg >= 0, "lipasr_mlp_train_segment_exchange: bad argument");
+  *floats = 0;
+  int cur = 0;
+  for (int l = 0; l + 1 < m->n_layers; ++l)  // forward: layer l's GEMM closes a segment if layer l has BatchNorm
+    if (m->L[l].bn) {
+      if (cur == seg) { *floats = 2 * (size_t)stats_row_tiles(batch, m->L[l].n_out, m->L[l].n_in) * m->L[l].n_out; return LIPASR_OK; }
+      ++cur;
+    }
+  for (int l = m->n_layers - 1; l >= 1; --l)  // backward: the dX GEMM into layer l-1 closes one if layer l-1 has BatchNorm
+    if (m->L[l - 1].bn) {
+      if (cur == seg) { *floats = 2 * (size_t)stats_row_tiles(batch, m->L[l - 1].n_out, m->L[l].n_out) * m->L[l - 1].n_out; return LIPASR_OK; }
+      ++cur;
+    }
+  return LIPASR_OK;
+}
+
+int lipasr_mlp_part_floats(lipasr_mlp_t m, size_t* floats) {
+  LP_CHECK_ARG(m && floats, "lipasr_mlp_part_floats: null argument");
+  *floats = 2 * (size_t)((m->max_batch + 31) / 32) * m->max_width;
+  return LIPASR_OK;
+}
+
+int lipasr_mlp_train_segment(lipasr_mlp_t m, int seg, const float* params, float* bnstate, const float* x, const float* y_onehot,
+                             int batch, float inv_batch, const lipasr_dropout_cfg* dropout, float* grads, float* loss_rows,
+                             float* correct_rows, float* probs, float* part, int stat_batch, float stat_grad_scale,
+                             lipasr_stream_t stream) {
+  LP_CHECK_ARG(m != nullptr && part != nullptr, "lipasr_mlp_train_segment: null argument");
+  int n = 0;
+  (void)lipasr_mlp_train_segments(m, &n);
+  LP_CHECK_ARG(seg >= 0 && seg < n, "lipasr_mlp_train_segment: segment %d outside [0, %d)", seg, n);
+  LP_CHECK_ARG(stat_batch >= batch && stat_grad_scale > 0.0f, "lipasr_mlp_train_segment: stat_batch=%d (< batch %d) or scale %g", stat_batch,
+               batch, (double)stat_grad_scale);
+  SegArgs sa;
+  sa.seg = seg; sa.part_ext = part; sa.stat_batch = stat_batch; sa.grad_scale = stat_grad_scale;
+  return train_fwd_bwd_impl(m, params, bnstate, x, y_onehot, batch, inv_batch, dropout, grads, loss_rows, correct_rows, probs,
+                            stream, 0, sa);
 }
 
 int lipasr_mlp_grad_split(lipasr_mlp_t m, size_t* late_floats) {

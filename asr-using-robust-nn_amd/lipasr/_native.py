@@ -80,6 +80,10 @@ PROTOTYPES = {
     "lipasr_mlp_train_fwd_bwd_head": (i32, [c_h, c_f, c_f, c_f, c_f, i32, f32, C.POINTER(DropoutCfg), c_f, c_f, c_f, c_f, c_s]),
     "lipasr_mlp_train_dw0": (i32, [c_h, c_f, i32, c_f, c_s]),
     "lipasr_mlp_grad_split": (i32, [c_h, C.POINTER(sz)]),
+    "lipasr_mlp_train_segments": (i32, [c_h, PI]),
+    "lipasr_mlp_train_segment_exchange": (i32, [c_h, i32, i32, C.POINTER(sz)]),
+    "lipasr_mlp_part_floats": (i32, [c_h, C.POINTER(sz)]),
+    "lipasr_mlp_train_segment": (i32, [c_h, i32, c_f, c_f, c_f, c_f, i32, f32, C.POINTER(DropoutCfg), c_f, c_f, c_f, c_f, c_f, i32, f32, c_s]),
     "lipasr_mlp_adam_nonneg": (i32, [c_h, c_f, c_f, c_f, c_f, c_f, f32, f32, f32, f32, f32, c_s]),
     "lipasr_mlp_project_product": (i32, [c_h, c_f, f32, PI, i32, c_f, c_s]),
     "lipasr_mlp_adam_project_product": (i32, [c_h, c_f, c_f, c_f, c_f, c_f, f32, f32, f32, f32, f32, f32, PI, i32, c_f, c_s]),

@@ -497,6 +497,30 @@ class Model:
                    C.byref(cfg), N.ptr(self._grads), N.ptr(self._loss_rows), N.ptr(self._correct_rows),
                    N.ptr(probs), N.stream_ptr()))
 
+    def train_fwd_bwd_syncbn(self, xb, yb, dp, global_batch, masks=None, dropout=True, probs=None):
+        """Synchronized BatchNorm (opt-in): the same kernels as train_fwd_bwd, run segment by segment with a SUM all-reduce
+        of the BatchNorm column partial sums between segments (``dp``: lipasr.parallel.DataParallel), so that every rank
+        normalises with the statistics of the GLOBAL batch, as the single-device reference does.  Eager (no HIP graph):
+        2 x (BatchNorm layers) small collectives per step."""
+        bsz = xb.shape[0]
+        cfg = self._dropout_cfg(masks, dropout)
+        if getattr(self, "_part", None) is None:
+            n = N.sz()
+            N.check(N.lib.lipasr_mlp_part_floats(self._plan, C.byref(n)))
+            self._part = torch.zeros(int(n.value), device=self._device)
+            ns = C.c_int()
+            N.check(N.lib.lipasr_mlp_train_segments(self._plan, C.byref(ns)))
+            self._n_segments = ns.value
+        for seg in range(self._n_segments):
+            N.check(N.lib.lipasr_mlp_train_segment(self._plan, seg, N.ptr(self._params), N.ptr(self._bnstate), N.ptr(xb), N.ptr(yb), bsz,
+                                                   1.0 / float(global_batch), C.byref(cfg), N.ptr(self._grads), N.ptr(self._loss_rows),
+                                                   N.ptr(self._correct_rows), N.ptr(probs), N.ptr(self._part), int(global_batch),
+                                                   1.0 / float(dp.world), N.stream_ptr()))
+            n = N.sz()
+            N.check(N.lib.lipasr_mlp_train_segment_exchange(self._plan, bsz, seg, C.byref(n)))
+            if n.value:
+                dp.allreduce_grads(self._part[:int(n.value)])
+
     def train_dw0(self, xb):
         N.check(N.lib.lipasr_mlp_train_dw0(self._plan, N.ptr(xb), xb.shape[0], N.ptr(self._grads), N.stream_ptr()))
 

@@ -5,7 +5,8 @@ batch factor folded into the loss gradient, then Adam + NonNeg + the Lipschitz p
 redundantly and deterministically on every replica (no second exchange; the kernels use no float
 atomics, so replicas stay bit-identical).  The exchange goes in two buckets so that 44 % of it overlaps the
 first layer's weight-gradient GEMM (train_step_overlapped / TrainPipeline).  BatchNorm statistics are per
-replica (tests/test_dp_gloo.py and tests/test_dp_gpu.py check accuracy parity with the single-process run);
+replica by default (tests/test_dp_gloo.py and tests/test_dp_gpu.py check accuracy parity with the single-process run;
+``sync_bn=True`` exchanges the column partial sums instead, for runs that must match the single device exactly);
 every rank draws its own dropout masks (the rank is folded into the Philox key).
 
 The reference has no counterpart (single process, train_constraints.py:91-105).
@@ -101,14 +102,18 @@ class DataParallel:
             return _Done()
         return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
-    def train_step(self, replica, xb, yb, global_batch=None, **kw):
+    def train_step(self, replica, xb, yb, global_batch=None, sync_bn=False, **kw):
         """xb, yb: this rank's shard.  Per-replica gradients carry 1/global_batch, so their SUM is the
-        gradient of the mean loss over the global batch."""
+        gradient of the mean loss over the global batch.  sync_bn: BatchNorm statistics over the GLOBAL batch
+        (``replica.train_fwd_bwd_syncbn``: 2 small all-reduces per BatchNorm layer) instead of per replica."""
         if global_batch is None:
             global_batch = self.global_count(xb.shape[0])
         if hasattr(replica, "_replica_rank"):
             replica._replica_rank = self.rank  # every rank its own dropout masks
-        replica.train_fwd_bwd(xb, yb, inv_batch=1.0 / float(global_batch), **kw)
+        if sync_bn and self.world > 1:
+            replica.train_fwd_bwd_syncbn(xb, yb, self, global_batch, **kw)
+        else:
+            replica.train_fwd_bwd(xb, yb, inv_batch=1.0 / float(global_batch), **kw)
         self.allreduce_grads(replica.grads)
         replica.apply_adam()
 

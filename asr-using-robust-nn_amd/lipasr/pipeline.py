@@ -26,7 +26,8 @@ from .parallel import DataParallel
 
 class TrainPipeline:
     def __init__(self, model, batch, sr_in=16000, n_samp=16000, utterance_length=44, rho=0.1, constraint="product",
-                 affine=None, pgd=None, dp=None, use_graph=True, per_layer_iters=4, extractor=None, mfcc_cus="auto", sync_inputs=True, overlap_buckets=False):
+                 affine=None, pgd=None, dp=None, use_graph=True, per_layer_iters=4, extractor=None, mfcc_cus="auto",
+                 sync_inputs=True, overlap_buckets=False, sync_bn=False):
         """constraint: 'product' (simple_norm_constraint, all layers), 'per_layer' (norm_constraint) or None.
         affine: (mean, scale) float64 device tensors [20*utterance_length] or None.
         pgd: dict(eps=, eps_step=, max_iter=) for adversarial training on the standardised features.
@@ -45,6 +46,8 @@ class TrainPipeline:
         # graph boundary and the second collective's stream hand-offs cost +57 us per step against +14 us for the
         # one-collective schedule, more than the ~36 us of wire time the overlap can hide at this message size.
         self.overlap_buckets = bool(overlap_buckets)
+        # Data parallel, BatchNorm: per-replica statistics (default; accuracy parity shown in tests/test_dp_gpu.py) or, opt-in,
+        # statistics of the global batch through 2 small all-reduces per BatchNorm layer (eager launches, no HIP graph): set below
         self.model, self.batch, self.L = model, int(batch), int(utterance_length)
         self.dev = model._device
         self.h = N.get_handle(self.dev.index)
@@ -54,6 +57,7 @@ class TrainPipeline:
         self.dp = dp if dp is not None else DataParallel()
         model._replica_rank = self.dp.rank  # every rank draws its own dropout masks
         self._late = model.late_floats      # [dW_0 | db_0]: the gradient bucket that is ready last
+        self.sync_bn = bool(sync_bn) and self.dp.world > 1
         self.use_graph = use_graph
         self.per_layer_iters = per_layer_iters
         self.mean, self.scale = affine if affine is not None else (None, None)
@@ -248,7 +252,13 @@ class TrainPipeline:
                 prof = self._prof[self._prof_i]
                 self._prof_i += 1
                 prof[0].record(self.stream)
-            if not self.use_graph:
+            if self.sync_bn:
+                if self.pgd:
+                    raise NotImplementedError("sync_bn with the PGD inner loop")
+                self.model.train_fwd_bwd_syncbn(self._feats2[b][:bsz], self._labels2[b][:bsz], self.dp, gb)
+                self.dp.allreduce_grads(self.model._grads)
+                self._update()
+            elif not self.use_graph:
                 if self.dp.world == 1:
                     self._attack_and_train(bsz, b, gb)
                     self._update()

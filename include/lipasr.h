@@ -213,6 +213,24 @@ int lipasr_mlp_train_fwd_bwd_head(lipasr_mlp_t m, const float* params, float* bn
 int lipasr_mlp_train_dw0(lipasr_mlp_t m, const float* x, int batch, float* grads, lipasr_stream_t stream);
 int lipasr_mlp_grad_split(lipasr_mlp_t m, size_t* late_floats);
 
+/* Synchronized BatchNorm under data parallelism (opt-in, for runs that must reproduce the single-device statistics of
+ * train_constraints.py:68-83 exactly; the default is per-replica statistics): lipasr_mlp_train_fwd_bwd cut into
+ * segments that end right after each GEMM whose epilogue leaves BatchNorm column partial sums -- sums of a and a^2 in the
+ * forward pass, of g and g xhat in the backward pass -- i.e. before the kernel that consumes them.  The caller runs
+ * segment 0 .. n-1 in order and, after segment s, SUM-all-reduces the first lipasr_mlp_train_segment_exchange(m, batch, s)
+ * floats of `part` across the ranks (0 floats after the last).  part: caller-owned device buffer of
+ * lipasr_mlp_part_floats(m) floats; stat_batch: rows of the GLOBAL batch (the statistics' denominator);
+ * stat_grad_scale: 1 / world (dgamma / dbeta are computed from the already-global sums and are summed again by the
+ * gradient all-reduce).  The reference model has 5 BatchNorm layers: 11 segments, 10 exchanges of <= 64 kB. */
+int lipasr_mlp_train_segments(lipasr_mlp_t m, int* n_segments);
+int lipasr_mlp_train_segment_exchange(lipasr_mlp_t m, int batch, int seg, size_t* floats);
+int lipasr_mlp_part_floats(lipasr_mlp_t m, size_t* floats);
+int lipasr_mlp_train_segment(lipasr_mlp_t m, int seg, const float* params, float* bnstate, const float* x,
+                             const float* y_onehot, int batch, float inv_batch,
+                             const lipasr_dropout_cfg* dropout, float* grads, float* loss_rows,
+                             float* correct_rows, float* probs, float* part, int stat_batch,
+                             float stat_grad_scale, lipasr_stream_t stream);
+
 /* K5: Keras Adam (optimizer='adam', train_constraints.py:94) then NonNeg (:67-85) in one launch
  * over the flat buffers: g' = g*grad_scale; m = b1 m + (1-b1) g'; v = b2 v + (1-b2) g'^2;
  * w -= lr*sqrt(1-b2^t)/(1-b1^t) * m / (sqrt(v) + eps); then w = w*[w>=0] on NonNeg kernels.

@@ -203,3 +203,72 @@ def test_head_plus_dw0_equals_one_call(cuda):
     d = (m2._grads[:late] - whole[:late]).abs().max() / whole[:late].abs().max()
     assert float(d) < 2e-5, float(d)
     assert torch.equal(m2._bnstate, bn)
+
+
+# ------------------------------------------------------------------ synchronized BatchNorm (opt-in)
+def _sync_run(dp, sync_bn, steps=4):
+    from helpers import build_model, dev, load_params
+    from lipasr.pipeline import TrainPipeline
+    from oracle import mlp_ref as P
+
+    # the reference's constrained model with its five BatchNorm layers, dropout off so that runs are comparable bit for bit
+    spec = [P.LayerSpec(s.n_in, s.n_out, s.bn, 0.0, s.nonneg) for s in P.vd_constrained_spec()]
+    m = build_model(spec, max_batch=64)
+    load_params(m, P.init_params(spec, seed=6, dtype=np.float32, nonneg_init=True))
+    rng = np.random.default_rng(17)
+    x = dev(rng.standard_normal((64 * steps, 880)))
+    y = dev(P.to_categorical(rng.integers(0, 10, 64 * steps), 10))
+    per = 64 // dp.world
+    pipe = TrainPipeline(m, batch=per, rho=0.1, constraint="product", dp=dp, use_graph=True, sync_bn=sync_bn)
+    for s in range(steps):
+        xb, yb = dp.shard(x[64 * s:64 * (s + 1)], y[64 * s:64 * (s + 1)])
+        pipe.step(None, yb.contiguous(), features=xb.contiguous())
+    pipe.synchronize()
+    return m, pipe
+
+
+def _sync_worker(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "asr-using-robust-nn_amd"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from lipasr.parallel import DataParallel, init_from_env
+
+    torch.cuda.set_device(0)
+    init_from_env("gloo")
+    dp = DataParallel()
+    out = {}
+    for sync in (True, False):
+        m, pipe = _sync_run(dp, sync)
+        out[sync] = {"params": m._params.cpu(), "bn": m._bnstate.cpu(), "div": dp.max_divergence(m._params), "norms": pipe.norms.cpu()}
+        pipe.close()
+    torch.save(out, os.path.join(out_dir, f"s{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_sync_batchnorm_two_ranks_match_one_rank(cuda, tmp_path):
+    """Opt-in synchronized BatchNorm (lipasr_mlp_train_segment + a SUM all-reduce of the column partial sums between
+    segments): two ranks of 32 rows reproduce the single process's 64-row run of the five-BatchNorm model -- weights AND
+    moving statistics -- to fp32 summation order, which per-replica statistics (the default) do not."""
+    from lipasr.parallel import DataParallel
+
+    m1, pipe1 = _sync_run(DataParallel(), False)
+    ref, ref_bn = m1._params.cpu(), m1._bnstate.cpu()
+    mp.spawn(_sync_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "s0.pt")
+    r1 = torch.load(tmp_path / "s1.pt")
+    for sync in (True, False):
+        assert r0[sync]["div"] == 0.0 and r1[sync]["div"] == 0.0
+    assert torch.equal(r0[True]["bn"], r1[True]["bn"])  # synchronized: identical moving statistics on both ranks
+    scale = ref.abs().max()
+    d_sync = ((r0[True]["params"] - ref).abs() / scale)
+    d_rep = ((r0[False]["params"] - ref).abs() / scale)
+    bn_sync = (r0[True]["bn"] - ref_bn).abs().max() / ref_bn.abs().max()
+    bn_rep = (r0[False]["bn"] - ref_bn).abs().max() / ref_bn.abs().max()
+    print(f"\nSyncBN vs 1 rank: params q999 {float(d_sync.quantile(0.999)):.2e} max {float(d_sync.max()):.2e}, moving stats {float(bn_sync):.2e}; "
+          f"per-replica BN: params q999 {float(d_rep.quantile(0.999)):.2e}, moving stats {float(bn_rep):.2e}")
+    assert float(bn_sync) < 1e-5                      # the statistics ARE the global batch's
+    assert float(d_sync.quantile(0.999)) < 1e-4       # as tight as the no-BatchNorm parity test above
+    assert float(bn_rep) > 10 * float(bn_sync)        # ... which per-replica statistics are not
+    torch.testing.assert_close(r0[True]["norms"], pipe1.norms.cpu(), rtol=1e-3, atol=0)
