@@ -34,6 +34,7 @@ struct MfccPlan {
   float* d_h = nullptr;   // [up][taps]
   int* d_noff = nullptr;  // [up]
   float* d_hband = nullptr;  // [n_ptiles][kRsBand][32]: banded taps of 32-phase tiles (MFMA resampler)
+  unsigned int* d_hbandh = nullptr;  // [n_ptiles][2 planes][kRhChunks][64 lanes][8 fp16]: the same taps x 8 as fp16 hi / lo fragments
   int* d_lo = nullptr;       // [n_ptiles]: n_off of each tile's first phase
   int n_ptiles = 0;
   int stage_mask = 0;        // debug/profiling: bit0 skip FFT passes, bit1 skip mel, bit2 use the VALU resampler
@@ -68,7 +69,7 @@ struct MfccPlan {
 
 void mfcc_plan_free(MfccPlan* p) {
   if (!p) return;
-  void* ptrs[] = {p->d_groups, p->d_dft, p->d_twB, p->d_mel_wlo, p->d_mel_whi, p->d_mel_pstart, p->d_mel_plen, p->d_hband, p->d_lo, p->d_h, p->d_noff, p->d_hann, p->d_tw, p->d_mel_start, p->d_mel_len, p->d_mel_off,
+  void* ptrs[] = {p->d_hbandh, p->d_groups, p->d_dft, p->d_twB, p->d_mel_wlo, p->d_mel_whi, p->d_mel_pstart, p->d_mel_plen, p->d_hband, p->d_lo, p->d_h, p->d_noff, p->d_hann, p->d_tw, p->d_mel_start, p->d_mel_len, p->d_mel_off,
                   p->d_mel_w, p->d_dct, p->d_y, p->d_db, p->d_fmax};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
@@ -340,6 +341,140 @@ void resample_persist_kernel(const float* __restrict__ x, int n_samp, int batch,
     }
     if (more) deposit(xs2 + (cur ^ 1) * 32 * kRsStride);  // the other buffer: nobody reads it during this q-block
     // LDS-only barrier: __syncthreads() would also wait for this q-block's output stores to reach memory
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    cur ^= 1;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// stage 1, persistent MFMA form on the fp16 matrix instruction (round 3).  Same schedule as resample_persist_kernel; the
+// contraction Y[32 clips][32 phases] = X[32][band] . Hband[band][32] runs on v_mfma_f32_32x32x16_f16 with BOTH operands
+// split into two fp16 planes, x = x_hi + x_lo, h = h_hi + h_lo (hi = the value rounded to fp16's 11 significant bits, lo =
+// the fp16 rounding of the remainder: 22 bits between them), and three of the four cross terms accumulated in fp32:
+//       x h  ~=  x_hi h_hi + x_hi h_lo + x_lo h_hi          (dropped: x_lo h_lo <= 2^-22 |x h|)
+// Every product of two fp16 numbers is exact in fp32, so the error is the 2^-22 of the two representations and of the
+// dropped term: <= 3 x 2.4e-7 x sum |x h| <= 1e-6 per output sample in the worst case, 1e-7 typically -- the fp32 kernel's
+// own accumulation error is 6e-8 x sqrt(128).  tests: 2e-6 against the float64 oracle, as for the fp32 kernel, which stays
+// the parity reference (stage-mask bit 4).  Cost: 3 matrix instructions of 32 cycles per 16 taps instead of 8 of 64 cycles
+// (v_mfma_f32_32x32x2_f32): 5.3x less matrix-pipe time (44 us of the fp32 kernel's 87 us per 1024 clips were MFMA-busy).
+// fp16's exponent range is short: the low plane of a value below 2^-14 x 2^11 = 0.125 falls on the subnormal grid (step
+// 2^-24) and a quiet passage at -60 dB would come out with a relative error of 1e-4.  So both operands are scaled by powers
+// of two before the split -- the samples by 2^11 (full 22-bit precision down to |x| = 6e-5 = -84 dB, an absolute floor of
+// 1.5e-11 below that; |x| must stay below 32, audio is in [-1, 1)), the taps by 2^6 -- and the accumulator by 2^-17
+// afterwards (all exact).  The band of a phase tile starts at a multiple of 8
+// samples (16-byte aligned ds_read_b128 of 8 consecutive fp16) and is padded to 160 = 10 k-steps.
+// LDS per window: 32 rows x {hi[480] | lo[480]} fp16 + 16 bytes = 1936 B per row (121 x 16: the 32 rows of a b128 read
+// fall on different bank quads), the same 62 kB as the fp32 window, double-buffered.
+// ---------------------------------------------------------------------------------------------
+typedef _Float16 rs_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 rs_h4 __attribute__((ext_vector_type(4)));
+constexpr int kRhK = 160, kRhChunks = kRhK / 16, kRhRowHalfs = 480, kRhRowBytes = 2 * kRhRowHalfs * 2 + 16;
+constexpr float kRhTapScale = 64.0f, kRhSigScale = 2048.0f;
+
+__global__ __launch_bounds__(64 * kRpMaxWaves) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void resample_persist_h2_kernel(const float* __restrict__ x, int n_samp, int batch, float* __restrict__ y, int n_valid, int n_y,
+                                int up, int down, int left, int nq, int n_tiles, const uint4* __restrict__ HbandH,
+                                const int* __restrict__ lo, int n_ptiles_rt) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char xh[];  // [2][32][kRhRowBytes]
+  const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // = phase tile
+  const int li = lane & 31, h = lane >> 5;
+  const int W = gridDim.x, T = n_tiles;
+  const int tile = (int)(((long)blockIdx.x * T) / W);
+  const int first = (int)(((long)tile * W + T - 1) / T), next = (int)(((long)(tile + 1) * W + T - 1) / T);
+  const int n_ranges = next - first, ri = blockIdx.x - first;
+  const int q_begin = (int)(((long)ri * nq) / n_ranges), q_end = (int)(((long)(ri + 1) * nq) / n_ranges);
+  const int u0 = tile * 32;
+  constexpr int kVecPerRow = kRhRowHalfs / 4;  // 120 float4 per row
+  constexpr int kFillMax = 4;  // 16 wavefronts fill (3840 float4 over 1024 threads); the first n_ptiles of them also multiply
+  const bool mm = wave < n_ptiles_rt;
+  // tap fragments of this wavefront's phase tile, both planes: loaded once  [tile][plane][chunk][lane] x 16 bytes
+  rs_h8 bh[kRhChunks], bl[kRhChunks];
+  if (mm) {
+    const uint4* hb = HbandH + ((size_t)wave * 2 * kRhChunks) * 64 + lane;
+#pragma unroll
+    for (int c = 0; c < kRhChunks; ++c) {
+      const uint4 t0 = hb[c * 64], t1 = hb[(kRhChunks + c) * 64];
+      bh[c] = __builtin_bit_cast(rs_h8, t0);
+      bl[c] = __builtin_bit_cast(rs_h8, t1);
+    }
+  }
+  const int band0 = mm ? ((lo[wave] + 1) & ~7) : 0;  // first sample of the band in the window, a multiple of 8
+  float4 stage[kFillMax];
+  auto fetch = [&](int q) {
+    const int base = down * q - left;
+    int tq = tid;
+    asm volatile("" : "+v"(tq));
+#pragma unroll
+    for (int j = 0; j < kFillMax; ++j) {
+      const int f = tq + j * nthreads;
+      const int i = f / kVecPerRow, v = f - i * kVecPerRow;
+      const int u = u0 + i, n = base + 4 * v;
+      stage[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (f < 32 * kVecPerRow && u < batch && n >= 0 && n + 3 < n_samp)
+        stage[j] = *reinterpret_cast<const float4*>(x + (size_t)u * n_samp + n);
+    }
+  };
+  auto deposit = [&](unsigned char* xs) {
+    int tq = tid;
+    asm volatile("" : "+v"(tq));
+#pragma unroll
+    for (int j = 0; j < kFillMax; ++j) {
+      const int f = tq + j * nthreads;
+      if (f < 32 * kVecPerRow) {
+        const int i = f / kVecPerRow, v = f - i * kVecPerRow;
+        const float e[4] = {stage[j].x, stage[j].y, stage[j].z, stage[j].w};
+        rs_h4 hi, lw;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float sc = fminf(fmaxf(e[c] * kRhSigScale, -65000.0f), 65000.0f);
+          const _Float16 a = (_Float16)sc;
+          hi[c] = a;
+          lw[c] = (_Float16)(sc - (float)a);
+        }
+        unsigned char* d = xs + i * kRhRowBytes + 8 * v;
+        *reinterpret_cast<rs_h4*>(d) = hi;
+        *reinterpret_cast<rs_h4*>(d + 2 * kRhRowHalfs) = lw;
+      }
+    }
+  };
+  if (q_begin < q_end) {
+    fetch(q_begin);
+    deposit(xh);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int q = q_begin; q < q_end; ++q) {
+    const bool more = q + 1 < q_end;
+    if (more) fetch(q + 1);
+    const unsigned char* xa = xh + cur * 32 * kRhRowBytes + li * kRhRowBytes + 2 * (band0 + 8 * h);
+    rs_f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+    if (mm) {
+#pragma unroll
+    for (int c = 0; c < kRhChunks; ++c) {
+      const rs_h8 ah = *reinterpret_cast<const rs_h8*>(xa + 32 * c);
+      const rs_h8 al = *reinterpret_cast<const rs_h8*>(xa + 32 * c + 2 * kRhRowHalfs);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[c], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[c], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[c], acc, 0, 0, 0);
+    }
+    }
+    const int pp = 32 * wave + li;
+    const int t = q * up + pp;
+    if (mm && pp < up && t < n_y) {
+      float* yb = y + (size_t)u0 * n_y;
+      int off = 4 * h * n_y + t;
+      asm volatile("" : "+v"(off));
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2);
+        if (u0 + row + 4 * h < batch) yb[off + row * n_y] = t < n_valid ? acc[e] * (1.0f / (kRhTapScale * kRhSigScale)) : 0.0f;
+      }
+    }
+    if (more) deposit(xh + (cur ^ 1) * 32 * kRhRowBytes);
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
     __builtin_amdgcn_s_barrier();
     cur ^= 1;
@@ -793,19 +928,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     for (int r = 1; r < 4; ++r) { va[r] = mulw(va[r], wa[r - 1]); vb[r] = mulw(vb[r], wb[r - 1]); }
     dft4_2(va);
     dft4_2(vb);
+    // only the upper half of the spectrum goes back to LDS: the partners Z[2048 - k] of the bins k <= 1024 live there
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { st4(pa + 512 * r, va[r]); st4(pb + 512 * r, vb[r]); }
+    for (int r = 2; r < 4; ++r) { st4(pa + 512 * r, va[r]); st4(pb + 512 * r, vb[r]); }
   }
   lds_barrier2();
   // ---- separation by conjugate symmetry, powers, the two mel weights of each bin.  Z[k] is in registers (above); the
-  // partner Z[2048 - k] belongs to another thread and comes from LDS.
+  // partner Z[2048 - k] belongs to another thread and comes from LDS (k = 0 is its own partner).
   float4 zc[5];
 #pragma unroll
   for (int i = 0; i < 5; ++i) {
     const int kb = tid + 256 * i;
     if (kb <= 1024) {
-      const int kc = (2048 - kb) & 2047;
-      zc[i] = buf[kc ^ (((kc >> 4) & 3) << 1)];
+      const int kc = 2048 - kb;  // 1024 .. 2048
+      if (kb == 0) zc[i] = make_float4(va[0].re.x, va[0].re.y, va[0].im.x, va[0].im.y);
+      else zc[i] = buf[kc ^ (((kc >> 4) & 3) << 1)];
     }
   }
   lds_barrier2();
@@ -1681,6 +1818,36 @@ static std::vector<int> build_groups(int n_y, int n_frames, int up) {
   return g;
 }
 
+// fp16 hi / lo fragments of the banded taps in the B-operand lane order of v_mfma_f32_32x32x16_f16: lane (col, h) of k-step c
+// holds B[k = 16 c + 8 h + j][col], j < 8; the band starts at the window position (lo + 1) & ~7
+static std::vector<unsigned int> build_band_h2(const std::vector<float>& hb, const std::vector<int>& lo) {
+  const int nt = (int)lo.size();
+  std::vector<unsigned int> out((size_t)nt * 2 * kRhChunks * 64 * 4, 0u);
+  for (int r = 0; r < nt; ++r) {
+    const int first = lo[r] + 1, band0 = first & ~7;
+    for (int c = 0; c < kRhChunks; ++c)
+      for (int ln = 0; ln < 64; ++ln) {
+        const int col = ln & 31, hh = ln >> 5;
+        unsigned short hi[8], lw[8];
+        for (int j = 0; j < 8; ++j) {
+          const int kk = band0 + 16 * c + 8 * hh + j - first;  // index into the 152-sample band of the fp32 table
+          const float v = (kk >= 0 && kk < kRsBand) ? hb[((size_t)r * kRsBand + kk) * 32 + col] * kRhTapScale : 0.0f;
+          const _Float16 a = (_Float16)v;
+          const _Float16 b = (_Float16)(v - (float)a);
+          memcpy(&hi[j], &a, 2);
+          memcpy(&lw[j], &b, 2);
+        }
+        unsigned int* dh = &out[((((size_t)r * 2 + 0) * kRhChunks + c) * 64 + ln) * 4];
+        unsigned int* dl = &out[((((size_t)r * 2 + 1) * kRhChunks + c) * 64 + ln) * 4];
+        for (int w = 0; w < 4; ++w) {
+          dh[w] = (unsigned int)hi[2 * w] | ((unsigned int)hi[2 * w + 1] << 16);
+          dl[w] = (unsigned int)lw[2 * w] | ((unsigned int)lw[2 * w + 1] << 16);
+        }
+      }
+  }
+  return out;
+}
+
 static int lo_max(const MfccPlan*, const Polyphase& pp) {
   int m = 0;
   for (int r = 0; 32 * r < pp.up; ++r) m = std::max(m, pp.n_off[32 * r]);
@@ -1717,6 +1884,19 @@ static int launch_resample(const MfccPlan* p, const float* wav, int batch, float
     int wgs = p->rs_target_wgs;  // one workgroup per CU this stream may use
     if (wgs < tiles) wgs = tiles;
     if (wgs > tiles * nq) wgs = tiles * nq;
+    if (p->d_hbandh && !(p->stage_mask & 16) && p->left == 64 && p->down + 128 + 32 <= kRhRowHalfs) {
+      const size_t ldsh = (size_t)2 * 32 * kRhRowBytes;
+      static bool attr_h = false;
+      if (!attr_h) {
+        LP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(resample_persist_h2_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsh));
+        attr_h = true;
+      }
+      hipLaunchKernelGGL(resample_persist_h2_kernel, dim3(wgs), dim3(64 * kRpMaxWaves), ldsh, st, wav, p->n_samp, batch, y,
+                         p->n_valid, p->n_y, p->up, p->down, p->left, nq, tiles, reinterpret_cast<const uint4*>(p->d_hbandh), p->d_lo, n_waves);
+      LP_LAUNCH_CHECK();
+      return LIPASR_OK;
+    }
     hipLaunchKernelGGL(resample_persist_kernel, dim3(wgs), dim3(64 * n_waves), lds, st, wav, p->n_samp, batch, y,
                        p->n_valid, p->n_y, p->up, p->down, p->left, nq, tiles, p->d_hband, p->d_lo);
   } else if (p->d_hband && !(p->stage_mask & 4)) {
@@ -1885,6 +2065,14 @@ static int plan_build(lipasr_handle_t h, int sr_in, int n_samp, int batch_max, i
           mfcc_plan_free(p);
           return rc;
         }
+        // fp16-plane fragments for resample_persist_h2_kernel: the band of every tile must fit 160 samples from its
+        // 8-aligned start and stay inside the 480-sample window
+        bool fits = true;
+        for (int r = 0; r < (int)lo.size(); ++r) {
+          const int first = lo[r] + 1, band0 = first & ~7;
+          fits = fits && (first - band0 + kRsBand <= kRhK) && (band0 + kRhK <= kRhRowHalfs);
+        }
+        if (fits && (rc = upload(&p->d_hbandh, build_band_h2(hb, lo))) != LIPASR_OK) { mfcc_plan_free(p); return rc; }
       }
     }
     // the fused resample -> STFT kernel: 2048/512 frames, 441 phases (16 kHz and 8 kHz input), rows 2 banks apart

@@ -292,3 +292,29 @@ def test_two_extractors_do_not_share_state(cuda):
     a.close(); b.close()
     with pytest.raises(Exception):
         a(dev(waves))
+
+
+def test_fp16_plane_resampler_against_fp32_kernel_and_oracle(cuda):
+    """resample_persist_h2_kernel (two fp16 planes per operand on v_mfma_f32_32x32x16_f16, three cross terms) against the exact
+    fp32 MFMA kernel (stage-mask bit 4, the parity reference) and the float64 oracle, on full-scale white noise -- the worst
+    case for the dropped 2^-22 terms -- and on quiet speech-like clips; 16 kHz and 8 kHz input."""
+    from lipasr.extract_features_construct_dataset import MfccExtractor
+    from lipasr.synth import synth_clips
+
+    rng = np.random.default_rng(5)
+    loud = rng.uniform(-1.0, 1.0, (6, 16000)).astype(np.float32)
+    quiet, _ = synth_clips(6, seed=8)
+    quiet = (1e-3 * quiet).astype(np.float32)
+    for sr, clips in ((16000, np.concatenate([loud, quiet])), (8000, np.concatenate([loud[:, :8000], quiet[:, :8000]]))):
+        ex = MfccExtractor(sr, clips.shape[1], 40)
+        y_h2 = ex.resample(dev(clips)).cpu().numpy()
+        ex.set(0, 16)
+        y_f32 = ex.resample(dev(clips)).cpu().numpy()
+        ex.set(0, 0)
+        ref = np.stack([M.librosa_load_resample(c, sr) for c in clips])
+        e_h2, e_f32 = np.abs(y_h2 - ref).max(axis=1), np.abs(y_f32 - ref).max(axis=1)
+        print(f"\nresampler {sr} Hz: max|err| vs float64 oracle  fp16-plane {e_h2[:6].max():.2e} (loud) {e_h2[6:].max():.2e} (quiet)   "
+              f"fp32 {e_f32[:6].max():.2e} / {e_f32[6:].max():.2e}")
+        assert e_f32.max() < 2e-6 and e_h2.max() < 2e-6
+        assert e_h2[6:].max() < 2e-9          # relative, not absolute: a clip at -60 dB is as accurate as a loud one
+        assert np.abs(y_h2 - y_f32).max() < 2e-6
