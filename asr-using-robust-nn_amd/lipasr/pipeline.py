@@ -107,7 +107,10 @@ class TrainPipeline:
             elif self._custom_ex:
                 mfcc_cus = (n_cu * 7) // 8
             else:
-                mfcc_cus = (n_cu * 3) // 4 if self.batch >= 768 else (n_cu * 5) // 8
+                # round 3 (resampler on the fp16 matrix instruction, dual-FFT STFT kernel: the MFCC needs 155 us of the
+                # whole chip instead of 240), 200-step runs: batch 1024: 0.499 / 0.460 / 0.481 / 0.493 / 0.499 ms with
+                # 96 / 128 / 160 / 192 / 224 CUs; batch 512: 0.341 with 128, 0.353 with 160 -> half the chip
+                mfcc_cus = n_cu // 2
         if not mfcc_cus or mfcc_cus >= n_cu:
             return torch.cuda.Stream(device=self.dev)
         # Measured on MI355X (scratch/cu_mask_probe.py): mask bits act in groups of 8 consecutive bits -- group g
