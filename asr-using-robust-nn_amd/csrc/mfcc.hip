@@ -375,9 +375,9 @@ constexpr float kRhTapScale = 64.0f, kRhSigScale = 2048.0f;
 __global__ __launch_bounds__(64 * kRpMaxWaves) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void resample_persist_h2_kernel(const float* __restrict__ x, int n_samp, int batch, float* __restrict__ y, int n_valid, int n_y,
                                 int up, int down, int left, int nq, int n_tiles, const uint4* __restrict__ HbandH,
-                                const int* __restrict__ lo, int n_ptiles_rt) {
+                                const int* __restrict__ lo, int n_ptiles_rt, int dbg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char xh[];  // [2][32][kRhRowBytes]
-  const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x;
+  const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // = phase tile
   const int li = lane & 31, h = lane >> 5;
   const int W = gridDim.x, T = n_tiles;
@@ -402,28 +402,25 @@ void resample_persist_h2_kernel(const float* __restrict__ x, int n_samp, int bat
   }
   const int band0 = mm ? ((lo[wave] + 1) & ~7) : 0;  // first sample of the band in the window, a multiple of 8
   float4 stage[kFillMax];
+  // Fill mapping without divisions: 32 threads per window row (1024 threads = 32 rows), thread (row, c) moves the float4
+  // columns c, c + 32, c + 64, c + 96 of its row (120 of the 128 exist): 512 contiguous bytes per row and instruction.
+  const int frow = tid >> 5, fcol = tid & 31;
   auto fetch = [&](int q) {
     const int base = down * q - left;
-    int tq = tid;
-    asm volatile("" : "+v"(tq));
+    const int u = u0 + frow;
+    const float* src = x + (size_t)u * n_samp + base;
 #pragma unroll
     for (int j = 0; j < kFillMax; ++j) {
-      const int f = tq + j * nthreads;
-      const int i = f / kVecPerRow, v = f - i * kVecPerRow;
-      const int u = u0 + i, n = base + 4 * v;
+      const int v = fcol + 32 * j, n = base + 4 * v;
       stage[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (f < 32 * kVecPerRow && u < batch && n >= 0 && n + 3 < n_samp)
-        stage[j] = *reinterpret_cast<const float4*>(x + (size_t)u * n_samp + n);
+      if (v < kVecPerRow && u < batch && n >= 0 && n + 3 < n_samp) stage[j] = *reinterpret_cast<const float4*>(src + 4 * v);
     }
   };
   auto deposit = [&](unsigned char* xs) {
-    int tq = tid;
-    asm volatile("" : "+v"(tq));
+    unsigned char* drow = xs + frow * kRhRowBytes + 8 * fcol;
 #pragma unroll
     for (int j = 0; j < kFillMax; ++j) {
-      const int f = tq + j * nthreads;
-      if (f < 32 * kVecPerRow) {
-        const int i = f / kVecPerRow, v = f - i * kVecPerRow;
+      if (fcol + 32 * j < kVecPerRow) {
         const float e[4] = {stage[j].x, stage[j].y, stage[j].z, stage[j].w};
         rs_h4 hi, lw;
 #pragma unroll
@@ -433,7 +430,7 @@ void resample_persist_h2_kernel(const float* __restrict__ x, int n_samp, int bat
           hi[c] = a;
           lw[c] = (_Float16)(sc - (float)a);
         }
-        unsigned char* d = xs + i * kRhRowBytes + 8 * v;
+        unsigned char* d = drow + 256 * j;
         *reinterpret_cast<rs_h4*>(d) = hi;
         *reinterpret_cast<rs_h4*>(d + 2 * kRhRowHalfs) = lw;
       }
@@ -446,13 +443,13 @@ void resample_persist_h2_kernel(const float* __restrict__ x, int n_samp, int bat
   __syncthreads();
   int cur = 0;
   for (int q = q_begin; q < q_end; ++q) {
-    const bool more = q + 1 < q_end;
+    const bool more = q + 1 < q_end && !(dbg & 4);  // (dbg: profiling switches, results wrong)
     if (more) fetch(q + 1);
     const unsigned char* xa = xh + cur * 32 * kRhRowBytes + li * kRhRowBytes + 2 * (band0 + 8 * h);
     rs_f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
-    if (mm) {
+    if (mm && !(dbg & 1)) {
 #pragma unroll
     for (int c = 0; c < kRhChunks; ++c) {
       const rs_h8 ah = *reinterpret_cast<const rs_h8*>(xa + 32 * c);
@@ -464,7 +461,7 @@ void resample_persist_h2_kernel(const float* __restrict__ x, int n_samp, int bat
     }
     const int pp = 32 * wave + li;
     const int t = q * up + pp;
-    if (mm && pp < up && t < n_y) {
+    if (mm && pp < up && t < n_y && !(dbg & 2)) {
       float* yb = y + (size_t)u0 * n_y;
       int off = 4 * h * n_y + t;
       asm volatile("" : "+v"(off));
@@ -1893,7 +1890,7 @@ static int launch_resample(const MfccPlan* p, const float* wav, int batch, float
         attr_h = true;
       }
       hipLaunchKernelGGL(resample_persist_h2_kernel, dim3(wgs), dim3(64 * kRpMaxWaves), ldsh, st, wav, p->n_samp, batch, y,
-                         p->n_valid, p->n_y, p->up, p->down, p->left, nq, tiles, reinterpret_cast<const uint4*>(p->d_hbandh), p->d_lo, n_waves);
+                         p->n_valid, p->n_y, p->up, p->down, p->left, nq, tiles, reinterpret_cast<const uint4*>(p->d_hbandh), p->d_lo, n_waves, (p->stage_mask >> 12) & 7);
       LP_LAUNCH_CHECK();
       return LIPASR_OK;
     }
