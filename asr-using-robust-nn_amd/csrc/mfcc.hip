@@ -807,27 +807,12 @@ __device__ __forceinline__ void lds_barrier2() {
   __builtin_amdgcn_s_barrier();
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void stft_mel2_kernel(StftArgs a) {
-  __shared__ __attribute__((aligned(16))) float4 buf[kF2Buf];
-  __shared__ __attribute__((aligned(16))) float4 rsum[2][128];  // run sums {f0, f2, f1, f3}: [weight array][run]
-  __shared__ float wmax[4][2];
-  const int tid = threadIdx.x, lane = tid & 63;
-  // XCD-aware block -> (clip, frame quad) map, as in stft_mel_kernel
-  int u, fq;
-  {
-    const int nq = gridDim.x, L = blockIdx.y * gridDim.x + blockIdx.x, nb = gridDim.y;
-    const int full = (nb / 8) * 8 * nq;
-    if (L < full) {
-      const int chunk = L >> 3;
-      u = (chunk / nq) * 8 + (L & 7);
-      fq = chunk % nq;
-    } else {
-      u = blockIdx.y;
-      fq = blockIdx.x;
-    }
-  }
-  const int f0 = 4 * fq;
-  const float* yu = a.y + (size_t)u * a.n_y;
+// Four frames (f0 .. f0 + 3) of clip u: two complex FFTs in packed lock step, powers, mel, dB.  On return thread (pr = tid >> 7,
+// m = tid & 127) holds the dB values of mel bin m for frames f0 + 2 pr (dbe) and f0 + 2 pr + 1 (dbo), which it has also
+// stored to a.db.  buf / rsum: the workgroup's LDS; every barrier inside is an LDS-only barrier.
+__device__ __forceinline__ void stft2_quad(const StftArgs& a, float4* __restrict__ buf, float4 (*__restrict__ rsum)[128],
+                                           const float* __restrict__ yu, int u, int f0, int tid, float& dbe, float& dbo) {
+  const int lane = tid & 63;
   // per-thread constants (L2-resident tables), on their way before the sample loads
   const int mel_part = (tid >> 6) & 1, mel_run = ((tid >> 7) << 6) + lane;
   const int mst = a.mel_start[mel_run], mln = a.mel_len[mel_run];
@@ -977,10 +962,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   float4 sum = rsum[0][m];
   if (m > 0) { const float4 h2 = rsum[1][m - 1]; sum.x += h2.x; sum.y += h2.y; sum.z += h2.z; sum.w += h2.w; }
   const float se = pr ? sum.y : sum.x, so = pr ? sum.w : sum.z;  // even / odd frame of the pair
-  const float dbe = 10.0f * log10f(fmaxf(1e-10f, se)), dbo = 10.0f * log10f(fmaxf(1e-10f, so));
+  dbe = 10.0f * log10f(fmaxf(1e-10f, se));
+  dbo = 10.0f * log10f(fmaxf(1e-10f, so));
   const int fe = f0 + 2 * pr, fo = fe + 1;
   if (fe < a.n_frames) a.db[((size_t)u * a.n_frames + fe) * 128 + m] = dbe;
   if (fo < a.n_frames) a.db[((size_t)u * a.n_frames + fo) * 128 + m] = dbo;
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void stft_mel2_kernel(StftArgs a) {
+  __shared__ __attribute__((aligned(16))) float4 buf[kF2Buf];
+  __shared__ __attribute__((aligned(16))) float4 rsum[2][128];  // run sums {f0, f2, f1, f3}: [weight array][run]
+  __shared__ float wmax[4][2];
+  const int tid = threadIdx.x, lane = tid & 63;
+  // XCD-aware block -> (clip, frame quad) map, as in stft_mel_kernel
+  int u, fq;
+  {
+    const int nq = gridDim.x, L = blockIdx.y * gridDim.x + blockIdx.x, nb = gridDim.y;
+    const int full = (nb / 8) * 8 * nq;
+    if (L < full) {
+      const int chunk = L >> 3;
+      u = (chunk / nq) * 8 + (L & 7);
+      fq = chunk % nq;
+    } else {
+      u = blockIdx.y;
+      fq = blockIdx.x;
+    }
+  }
+  const int f0 = 4 * fq;
+  const float* yu = a.y + (size_t)u * a.n_y;
+  float dbe, dbo;
+  stft2_quad(a, buf, rsum, yu, u, f0, tid, dbe, dbo);
   const float me = wave_max(dbe), mo = wave_max(dbo);
   if (lane == 0) { wmax[tid >> 6][0] = me; wmax[tid >> 6][1] = mo; }
   lds_barrier2();
@@ -1642,6 +1653,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 // ---------------------------------------------------------------------------------------------
 // stage 3: top_db floor, DCT, layout
 // ---------------------------------------------------------------------------------------------
+
 constexpr int kDctFrames = 64;  // frames per workgroup (blockIdx.y = chunk): LDS stays 33 kB whatever the clip length
 
 // One workgroup = one clip x 64 output frames, two wavefronts (32 frames each):
@@ -1890,7 +1902,7 @@ static int launch_resample(const MfccPlan* p, const float* wav, int batch, float
         attr_h = true;
       }
       hipLaunchKernelGGL(resample_persist_h2_kernel, dim3(wgs), dim3(64 * kRpMaxWaves), ldsh, st, wav, p->n_samp, batch, y,
-                         p->n_valid, p->n_y, p->up, p->down, p->left, nq, tiles, reinterpret_cast<const uint4*>(p->d_hbandh), p->d_lo, n_waves, (p->stage_mask >> 12) & 7);
+                         p->n_valid, p->n_y, p->up, p->down, p->left, nq, tiles, reinterpret_cast<const uint4*>(p->d_hbandh), p->d_lo, n_waves, (p->stage_mask >> 16) & 7);
       LP_LAUNCH_CHECK();
       return LIPASR_OK;
     }
