@@ -46,7 +46,6 @@ struct MfccPlan {
   bool prefer_fused = false;  // ... and uses it for plain float32 batches too (lipasr_mfcc_plan_set key 2)
   float* d_hann = nullptr;
   float* d_tw = nullptr;  // float2 [2048]
-  float* d_twB = nullptr; // float2 [32 r][32 k]: exp(-2 pi i r k / 1024) (pass B of the wave FFT)
   int* d_mel_start = nullptr;
   int* d_mel_len = nullptr;
   int* d_mel_off = nullptr;
@@ -69,7 +68,7 @@ struct MfccPlan {
 
 void mfcc_plan_free(MfccPlan* p) {
   if (!p) return;
-  void* ptrs[] = {p->d_hbandh, p->d_groups, p->d_dft, p->d_twB, p->d_mel_wlo, p->d_mel_whi, p->d_mel_pstart, p->d_mel_plen, p->d_hband, p->d_lo, p->d_h, p->d_noff, p->d_hann, p->d_tw, p->d_mel_start, p->d_mel_len, p->d_mel_off,
+  void* ptrs[] = {p->d_hbandh, p->d_groups, p->d_dft, p->d_mel_wlo, p->d_mel_whi, p->d_mel_pstart, p->d_mel_plen, p->d_hband, p->d_lo, p->d_h, p->d_noff, p->d_hann, p->d_tw, p->d_mel_start, p->d_mel_len, p->d_mel_off,
                   p->d_mel_w, p->d_dct, p->d_y, p->d_db, p->d_fmax};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
@@ -504,6 +503,12 @@ __device__ __forceinline__ int reflect_index(int j, int n) {
   return m < n ? m : period - m;
 }
 
+// the same for a clip longer than the padding (n > 2048 >= any |overshoot|): one reflection, no division
+__device__ __forceinline__ int reflect_once(int j, int n) {
+  const int lo = j < 0 ? -j : j;
+  return lo < n ? lo : 2 * (n - 1) - lo;
+}
+
 struct cpx { float re, im; };
 __device__ __forceinline__ cpx cadd(cpx a, cpx b) { return {a.re + b.re, a.im + b.im}; }
 __device__ __forceinline__ cpx csub(cpx a, cpx b) { return {a.re - b.re, a.im - b.im}; }
@@ -834,13 +839,26 @@ __device__ __forceinline__ void stft2_quad(const StftArgs& a, float4* __restrict
 #pragma unroll
     for (int e = 0; e < 8; ++e) x0[e] = {v2f{hw[e] * sm[e], hw[e] * sm[e + 4]}, v2f{hw[e] * sm[e + 2], hw[e] * sm[e + 6]}};
   } else {
+    // edge quads (2 of a 1-s clip's 11): the generic np.pad index costs a division per sample -- a quarter of the kernel's
+    // average instruction count when every edge quad paid it; clips longer than the padding reflect once
+    if (a.n_y > kNFft) {  // workgroup-uniform
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int j0 = f0 * 512 + tid + 256 * e - 1024;
-      float sj[4];
+      for (int e = 0; e < 8; ++e) {
+        const int j0 = f0 * 512 + tid + 256 * e - 1024;
+        float sj[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) sj[j] = (f0 + j < a.n_frames) ? yu[reflect_index(j0 + 512 * j, a.n_y)] : 0.0f;
-      x0[e] = {v2f{hw[e] * sj[0], hw[e] * sj[2]}, v2f{hw[e] * sj[1], hw[e] * sj[3]}};
+        for (int j = 0; j < 4; ++j) sj[j] = (f0 + j < a.n_frames) ? yu[reflect_once(j0 + 512 * j, a.n_y)] : 0.0f;
+        x0[e] = {v2f{hw[e] * sj[0], hw[e] * sj[2]}, v2f{hw[e] * sj[1], hw[e] * sj[3]}};
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int j0 = f0 * 512 + tid + 256 * e - 1024;
+        float sj[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sj[j] = (f0 + j < a.n_frames) ? yu[reflect_index(j0 + 512 * j, a.n_y)] : 0.0f;
+        x0[e] = {v2f{hw[e] * sj[0], hw[e] * sj[2]}, v2f{hw[e] * sj[1], hw[e] * sj[3]}};
+      }
     }
   }
   // ---- four passes.  Element e lives at float4 index swz(e) = e ^ (((e >> 4) & 3) << 1): inside every aligned block
@@ -1001,188 +1019,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   }
 }
 #undef LP_F2_PASS8
-
-// ---------------------------------------------------------------------------------------------
-// stage 2, wave-synchronous form: ONE wavefront per frame pair, no workgroup barrier anywhere.
-//   2048 = 32 x 32 x 2.  Each lane holds 32 complex points in registers:
-//     pass A  radix-32 butterfly on x[lane + 64 r]                      -> LDS [32 lane + q]
-//     pass B  radix-32 butterfly on (LDS[lane + 64 r]) * w1024^(r k)    -> LDS [(lane/32) 1024 + k + 32 q]
-//     pass C  16 radix-2 butterflies per lane with w2048^k
-//   The radix-32 butterfly is 8 DFT4 + 21 constant twiddles + 4 DFT8, all in registers (static indices).
-//   LDS exchanges are wave-private (in-order per wave), indices padded e + e/32 so that both the stride-32
-//   writes and the unit-stride reads of ds_*_b64 are conflict-free.  Separation, mel weights, the mel
-//   run sums, log and the per-frame max all stay inside the wave.  A workgroup is just 4 such waves
-//   (8 consecutive frames of one clip); LDS 17 kB per wave.
-// ---------------------------------------------------------------------------------------------
-constexpr int kWvBuf = 2128;   // float2 per wave: 2112 padded points, or 4 x 1060 weighted-power floats
-constexpr int kWvTS = 1060;    // stride of the four T arrays (padded bin index k + k/32 <= 1056)
-__device__ __forceinline__ int pad32(int e) { return e + (e >> 5); }
-
-constexpr float kW32c[22] = {1.f, 0.98078528f, 0.923879533f, 0.831469612f, 0.707106781f, 0.555570233f, 0.382683432f,
-                             0.195090322f, 0.f, -0.195090322f, -0.382683432f, -0.555570233f, -0.707106781f,
-                             -0.831469612f, -0.923879533f, -0.98078528f, -1.f, -0.98078528f, -0.923879533f,
-                             -0.831469612f, -0.707106781f, -0.555570233f};
-constexpr float kW32s[22] = {0.f, -0.195090322f, -0.382683432f, -0.555570233f, -0.707106781f, -0.831469612f,
-                             -0.923879533f, -0.98078528f, -1.f, -0.98078528f, -0.923879533f, -0.831469612f,
-                             -0.707106781f, -0.555570233f, -0.382683432f, -0.195090322f, 0.f, 0.195090322f,
-                             0.382683432f, 0.555570233f, 0.707106781f, 0.831469612f};
-
-// In-place radix-32 DFT (forward).  On return register position p = 8 q1 + q2 holds frequency q1 + 4 q2.
-__device__ __forceinline__ void dft32(cpx (&x)[32]) {
-#pragma unroll
-  for (int n2 = 0; n2 < 8; ++n2) {
-    cpx t[4] = {x[n2], x[8 + n2], x[16 + n2], x[24 + n2]};
-    dft4(t);
-    x[n2] = t[0];
-#pragma unroll
-    for (int q1 = 1; q1 < 4; ++q1) {
-      const int m = n2 * q1;  // <= 21
-      x[8 * q1 + n2] = (m == 0) ? t[q1] : cmul(t[q1], cpx{kW32c[m], kW32s[m]});
-    }
-  }
-#pragma unroll
-  for (int q1 = 0; q1 < 4; ++q1) {
-    cpx t[8];
-#pragma unroll
-    for (int n2 = 0; n2 < 8; ++n2) t[n2] = x[8 * q1 + n2];
-    dft8(t);
-#pragma unroll
-    for (int q2 = 0; q2 < 8; ++q2) x[8 * q1 + q2] = t[q2];
-  }
-}
-__device__ __forceinline__ constexpr int dft32_freq(int p) { return (p >> 3) + 4 * (p & 7); }
-
-__device__ __forceinline__ void wave_fence() {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
-
-__global__ __launch_bounds__(256) void stft_mel_wave_kernel(StftArgs a, const float2* __restrict__ twB) {
-  extern __shared__ __attribute__((aligned(16))) float2 wlds[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int u = blockIdx.y;
-  const int fp = blockIdx.x * 4 + wave;
-  if (fp >= (a.n_frames + 1) / 2) return;  // no workgroup barrier below: a whole wave may leave
-  float2* buf = wlds + wave * kWvBuf;
-  const int f0 = 2 * fp, f1 = f0 + 1;
-  const bool has1 = f1 < a.n_frames;
-  const float* yu = a.y + (size_t)u * a.n_y;
-
-  cpx v[32];
-#pragma unroll
-  for (int r = 0; r < 32; ++r) {
-    const int n = lane + 64 * r;
-    const float w = a.hann[n];
-    const int j0 = f0 * 512 + n - 1024;
-    const float s0 = yu[reflect_index(j0, a.n_y)];
-    const float s1 = has1 ? yu[reflect_index(j0 + 512, a.n_y)] : 0.0f;
-    v[r] = {w * s0, w * s1};
-  }
-  if (!(a.stage_mask & 1)) {
-    // ---- pass A
-    dft32(v);
-#pragma unroll
-    for (int p = 0; p < 32; ++p) buf[pad32(32 * lane + dft32_freq(p))] = make_float2(v[p].re, v[p].im);
-    wave_fence();
-    // ---- pass B
-    const int k = lane & 31;
-#pragma unroll
-    for (int r = 0; r < 32; ++r) {
-      const float2 t = buf[pad32(lane + 64 * r)];
-      v[r] = {t.x, t.y};
-    }
-#pragma unroll
-    for (int r = 1; r < 32; ++r) {
-      const float2 w = twB[r * 32 + k];
-      v[r] = cmul(v[r], cpx{w.x, w.y});
-    }
-    wave_fence();
-    dft32(v);
-    const int base = (lane >> 5) * 1024 + k;
-#pragma unroll
-    for (int p = 0; p < 32; ++p) buf[pad32(base + 32 * dft32_freq(p))] = make_float2(v[p].re, v[p].im);
-    wave_fence();
-    // ---- pass C: X[jj] and X[jj + 1024], jj = lane + 64 m, kept in v[m] and v[16 + m]
-#pragma unroll
-    for (int m = 0; m < 16; ++m) {
-      const int jj = lane + 64 * m;
-      const float2 ta = buf[pad32(jj)], tb = buf[pad32(jj + 1024)], w = a.tw[jj];
-      const cpx xa = {ta.x, ta.y};
-      const cpx xb = cmul(cpx{tb.x, tb.y}, cpx{w.x, w.y});
-      v[m] = cadd(xa, xb);
-      v[16 + m] = csub(xa, xb);
-    }
-    wave_fence();
-  }
-  // ---- spectrum back to LDS so that every lane can fetch the conjugate partner Z[2048 - k]
-#pragma unroll
-  for (int m = 0; m < 16; ++m) {
-    const int jj = lane + 64 * m;
-    buf[pad32(jj)] = make_float2(v[m].re, v[m].im);
-    buf[pad32(jj + 1024)] = make_float2(v[16 + m].re, v[16 + m].im);
-  }
-  wave_fence();
-  float2 zc[16];
-#pragma unroll
-  for (int m = 0; m < 16; ++m) zc[m] = buf[pad32((2048 - (lane + 64 * m)) & 2047)];
-  wave_fence();
-  // X0[k] = (Z[k] + conj Z[N-k])/2, X1[k] = (Z[k] - conj Z[N-k])/(2i); powers times the two mel weights of bin k
-  float* T = reinterpret_cast<float*>(buf);
-#pragma unroll
-  for (int m = 0; m < 16; ++m) {
-    const int kk = lane + 64 * m;
-    const float zr = v[m].re, zi = v[m].im, wr = zc[m].x, wi = -zc[m].y;
-    const float x0r = 0.5f * (zr + wr), x0i = 0.5f * (zi + wi);
-    const float x1r = 0.5f * (zi - wi), x1i = -0.5f * (zr - wr);
-    const float p0 = x0r * x0r + x0i * x0i, p1 = x1r * x1r + x1i * x1i;
-    const float wl = a.mel_wlo[kk], wh = a.mel_whi[kk];
-    const int pk = kk + (kk >> 5);
-    T[pk] = wl * p0;
-    T[kWvTS + pk] = wh * p0;
-    T[2 * kWvTS + pk] = wl * p1;
-    T[3 * kWvTS + pk] = wh * p1;
-  }
-  if (lane == 0) {
-    // Nyquist bin: Z[1024] is its own partner -> X0 = Re Z, X1 = Im Z
-    const float p0 = v[16].re * v[16].re, p1 = v[16].im * v[16].im;
-    const float wl = a.mel_wlo[1024], wh = a.mel_whi[1024];
-    const int pk = 1024 + 32;
-    T[pk] = wl * p0;
-    T[kWvTS + pk] = wh * p0;
-    T[2 * kWvTS + pk] = wl * p1;
-    T[3 * kWvTS + pk] = wh * p1;
-  }
-  wave_fence();
-  float fmx[2] = {-INFINITY, -INFINITY};
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int sel = t >> 1, m = lane + 64 * (t & 1);
-    const float* T1 = T + 2 * sel * kWvTS;
-    const float* T2 = T1 + kWvTS;
-    float s = 0.0f;
-    if (!(a.stage_mask & 2)) {
-      const int st = a.mel_start[m], ln = a.mel_len[m];
-      for (int i = 0; i < ln; ++i) { const int b = st + i; s += T1[b + (b >> 5)]; }
-      if (m > 0) {
-        const int st2 = a.mel_start[m - 1], ln2 = a.mel_len[m - 1];
-        float s2 = 0.0f;
-        for (int i = 0; i < ln2; ++i) { const int b = st2 + i; s2 += T2[b + (b >> 5)]; }
-        s += s2;
-      }
-    } else {
-      s = T1[m];
-    }
-    const float dbv = 10.0f * log10f(fmaxf(1e-10f, s));  // librosa.power_to_db(ref=1, amin=1e-10)
-    const int f = sel ? f1 : f0;
-    if (f < a.n_frames) a.db[((size_t)u * a.n_frames + f) * 128 + m] = dbv;
-    fmx[sel] = fmaxf(fmx[sel], dbv);
-  }
-  const float m0 = wave_max(fmx[0]), m1 = wave_max(fmx[1]);
-  if (lane == 0) {
-    a.fmax[(size_t)u * a.n_frames + f0] = m0;
-    if (has1) a.fmax[(size_t)u * a.n_frames + f1] = m1;
-  }
-}
 
 // ---------------------------------------------------------------------------------------------
 // stage 2 for a short window of any length (Speaker recognition/extract_features_construct_dataset.py:224-226:
@@ -1991,21 +1827,10 @@ static int launch_from_22k(const MfccPlan* p, const float* y, int batch, int L, 
       LP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dft_mel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)dl));
     hipLaunchKernelGGL(dft_mel_kernel, dim3((d.total_rows + kDftRows - 1) / kDftRows), dim3(64 * p->dft_tiles), dl, st, d);
-  } else if (!(p->stage_mask & (32 | 64 | 3))) {
+  } else if (!(p->stage_mask & (64 | 3))) {
     hipLaunchKernelGGL(stft_mel2_kernel, dim3((p->n_frames + 3) / 4, batch), dim3(256), 0, st, a);
-  } else if (!(p->stage_mask & 32)) {
-    hipLaunchKernelGGL(stft_mel_kernel, dim3((p->n_frames + 1) / 2, batch), dim3(256), 0, st, a);
   } else {
-    const size_t wl = (size_t)4 * kWvBuf * sizeof(float2);
-    static bool attr_set = false;
-    if (!attr_set) {
-      LP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(stft_mel_wave_kernel),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl));
-      attr_set = true;
-    }
-    const int npairs = (p->n_frames + 1) / 2;
-    hipLaunchKernelGGL(stft_mel_wave_kernel, dim3((npairs + 3) / 4, batch), dim3(256), wl, st, a,
-                       reinterpret_cast<const float2*>(p->d_twB));
+    hipLaunchKernelGGL(stft_mel_kernel, dim3((p->n_frames + 1) / 2, batch), dim3(256), 0, st, a);
   }
   LP_LAUNCH_CHECK();
   if (mid) LP_HIP(hipEventRecord(mid, st));
@@ -2094,16 +1919,6 @@ static int plan_build(lipasr_handle_t h, int sr_in, int n_samp, int batch_max, i
         p->fused = true;
       }
     }
-  }
-  {
-    std::vector<float> tb(2 * 32 * 32);
-    for (int r = 0; r < 32; ++r)
-      for (int k = 0; k < 32; ++k) {
-        const double ang = -2.0 * kPi * (double)(r * k) / 1024.0;
-        tb[2 * (r * 32 + k)] = (float)std::cos(ang);
-        tb[2 * (r * 32 + k) + 1] = (float)std::sin(ang);
-      }
-    if ((rc = upload(&p->d_twB, tb)) != LIPASR_OK) { mfcc_plan_free(p); return rc; }
   }
   MelSparse ms = mel_sparse(n_fft);
   if (dft) {

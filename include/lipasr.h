@@ -19,6 +19,9 @@
  *     launch function synchronises the device.
  *   - a handle / plan is re-entrant across handles, NOT thread-safe per handle:
  *     one handle per GPU per process (one process per GPU under data parallel).
+ *     The K3 entry points (projections, norms, lipasr_sv_clip) share the handle's 4 MiB
+ *     scratch: issue them on ONE stream per handle.  Classifier and MFCC plans own their
+ *     workspaces, so different plans may run on different streams.
  *   - Dense kernels use the Keras layout W(in, out), y = x @ W, row-major.
  */
 #ifndef LIPASR_H
