@@ -192,6 +192,35 @@ def register_owner(obj):
         _owners[:] = [r for r in _owners if r() is not None]
 
 
+# Native destroy calls free device memory (hipFree synchronises), which is illegal while THIS thread captures a HIP graph:
+# it invalidates the capture ("operation failed due to a previous error during capture").  Python finalisers run whenever
+# the garbage collector decides -- also in the middle of TrainPipeline._capture -- so every destroy goes through
+# destroy_or_defer(): during a capture it is parked and run right after the capture ends.
+_capture_depth = 0
+_deferred = []
+
+
+def capture_enter():
+    global _capture_depth
+    _capture_depth += 1
+
+
+def capture_exit():
+    global _capture_depth
+    _capture_depth = max(0, _capture_depth - 1)
+    if _capture_depth == 0:
+        pending, _deferred[:] = list(_deferred), []
+        for fn, args in pending:
+            fn(*args)
+
+
+def destroy_or_defer(fn, *args):
+    if _capture_depth > 0:
+        _deferred.append((fn, args))
+    else:
+        fn(*args)
+
+
 class Handle:
     """One lipasr handle per (process, device)."""
 
@@ -228,6 +257,14 @@ def shutdown():
     """Deterministic teardown: pipelines / models / extractors (newest first), then the handles -- graphs, CU-masked
     streams, plans, events, scratch -- all while the HIP runtime is still up.  Registered with atexit AFTER torch was
     imported, so it runs BEFORE torch's and the runtime's own exit handlers; safe to call more than once."""
+    global _capture_depth
+    _capture_depth = 0
+    pending, _deferred[:] = list(_deferred), []
+    for fn, args in pending:
+        try:
+            fn(*args)
+        except Exception:
+            pass
     owners, _owners[:] = list(_owners), []
     for ref in reversed(owners):
         obj = ref()

@@ -44,7 +44,7 @@ class MfccExtractor:
     def close(self):
         plan, self._plan = getattr(self, "_plan", None), None
         if plan and self.h.alive:
-            N.lib.lipasr_mfcc_destroy(plan)
+            N.destroy_or_defer(N.lib.lipasr_mfcc_destroy, plan)  # (a finaliser may run in the middle of a graph capture)
 
     def __del__(self):
         try:

@@ -416,7 +416,7 @@ class Model:
         """Frees the native classifier plan (its workspace).  Idempotent; the tensors stay readable."""
         plan, self._plan = getattr(self, "_plan", None), None
         if plan and self._h.alive:
-            N.lib.lipasr_mlp_destroy(plan)
+            N.destroy_or_defer(N.lib.lipasr_mlp_destroy, plan)  # (a finaliser may run in the middle of a graph capture)
 
     def __del__(self):
         try:

@@ -182,10 +182,14 @@ class TrainPipeline:
     def _capture(self, fn, *args):
         gid = C.c_int()
         N.check(N.lib.lipasr_graph_begin(self.h.h, N.stream_ptr()))
+        N.capture_enter()  # native destroys (finalisers the garbage collector may run now) wait until the capture is over
         try:
             fn(*args)
         finally:
-            N.check(N.lib.lipasr_graph_end(self.h.h, N.stream_ptr(), C.byref(gid)))
+            try:
+                N.check(N.lib.lipasr_graph_end(self.h.h, N.stream_ptr(), C.byref(gid)))
+            finally:
+                N.capture_exit()
         return gid.value
 
     def _warm_start(self):
@@ -317,6 +321,9 @@ class TrainPipeline:
         queue of its own) back, in that order.  Idempotent; also reached from ``lipasr._native.shutdown`` at interpreter
         exit, so no HIP object of the pipeline is left to the runtime's static destructors."""
         if getattr(self, "_closed", True):
+            return
+        if N._capture_depth > 0:  # a finaliser in the middle of another pipeline's capture: synchronising / freeing would break it
+            N._deferred.append((self.close, ()))
             return
         self._closed = True
         if not self.h.alive:  # the handle went first and took graphs and streams with it
