@@ -258,6 +258,34 @@ def _short(flags, batch, steps, warmup):
     return rec
 
 
+def run_fit_api(device, batch=512, n=16384, epochs=3):
+    """The reference-shaped entry as train_constraints.py:94-105 drives it: model.fit(dataset, callbacks=[simple_norm_constraint])
+    on pre-extracted standardised features, eager launches (one optimizer step, one callback, two metric reductions per
+    batch; no HIP graph).  Returns utterances/sec of the last epochs."""
+    from lipasr.Constraints import simple_norm_constraint
+    from lipasr.keras import CategoricalCrossentropy, Dataset
+    from lipasr.train_constraints import get_model
+
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = torch.randn(n, 880, generator=g).numpy()
+    lab = torch.randint(0, 10, (n,), generator=g).numpy()
+    y = np.zeros((n, 10), dtype=np.float32)
+    y[np.arange(n), lab] = 1
+    model = get_model(max_batch=batch, seed=0)
+    model.compile(optimizer="adam", loss=CategoricalCrossentropy(), metrics=["accuracy"])
+    ds = Dataset.from_tensor_slices((x, y)).batch(batch)
+    cb = simple_norm_constraint(rho=0.1, affected_layers_indices=[])
+    model.fit(ds, epochs=1, verbose=0, callbacks=[cb])  # warm-up (plans, first launches)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    model.fit(ds, epochs=epochs, verbose=0, callbacks=[cb])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    model.close()
+    return {"value": round(n * epochs / dt, 1), "unit": "utterances/sec", "ms_per_step": round(dt / (epochs * (n // batch)) * 1e3, 4),
+            "per_gpu_batch": batch, "what": "lipasr.keras.Model.fit + simple_norm_constraint callback, eager (the reference's own driver shape)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -274,6 +302,7 @@ def main():
     ap.add_argument("--pre-extracted", action="store_true", help="BASELINE config 2: train from resident (N,880) features, no MFCC stage")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--skip-b512", action="store_true")
+    ap.add_argument("--fit-api", action="store_true", help="only time the Keras-shaped fit() entry (used by the main run as a child process)")
     ap.add_argument("--skip-other-configs", action="store_true", help="do not add the config 2 / config 2 bf16 / config 5 records (N = 1 only)")
     args = ap.parse_args()
     opt = {"constraint": None if args.constraint == "none" else args.constraint, "pgd": args.pgd, "pgd_eps": args.pgd_eps, "bf16": args.bf16,
@@ -290,6 +319,9 @@ def main():
     device = torch.device("cuda", local)
     import torch.distributed as dist
 
+    if args.fit_api:
+        print(json.dumps(run_fit_api(device)), flush=True)
+        return
     batch = args.batch_per_gpu
     pool = make_pool(max(args.pool_clips, 8 * batch) // batch * batch, device, seed=1234 + rank)
     dt, ex = run_config(opt, pool, batch, rank, world, device, args.steps, args.warmup, profile=True)
@@ -311,11 +343,15 @@ def main():
     # HBM traffic of the stage per launch: PMC counters cannot be read from inside this process, so the value is
     # the committed rocprofv3 measurement of the same kernels (separate --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH
     # doubled per MI355X_MICROARCH.md), scaled to this batch.
-    traffic, traffic_src = None, None
+    traffic, traffic_src, traffic_fused = None, None, None
     for name in ("r03_mfcc_pmc.json", "r02_mfcc_pmc.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
-                traffic = round(json.load(f)["end_of_round"]["stage_bytes_per_utt"] * batch)
+                eor = json.load(f)["end_of_round"]
+            key = "fused_stage_bytes_per_utt" if ex.get("mfcc_fused") and "fused_stage_bytes_per_utt" in eor else "stage_bytes_per_utt"
+            traffic = round(eor[key] * batch)
+            if "fused_stage_bytes_per_utt" in eor:
+                traffic_fused = round(eor["fused_stage_bytes_per_utt"] * batch)
             traffic_src = f"profiles/{name} (rocprofv3 --pmc, per launch, scaled by batch)"
             break
         except Exception:
@@ -327,6 +363,8 @@ def main():
                 "algorithmic_bytes_per_utt": MFCC_BYTES_PER_UTT, "units_per_launch": batch,
                 "kernel_ms": {k: round(ms[k], 4) for k in ("resample", "stft_mel", "dct")},
                 "fp32_flop_frac": round(MFCC_FLOP_PER_UTT * batch / (stage_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 5) if stage_ms > 0 else 0.0,
+                "traffic_x_algorithmic": round(traffic / (MFCC_BYTES_PER_UTT * batch), 3) if traffic else None,
+                "fused_path_traffic": traffic_fused,  # the resample + STFT kernel (int16 / ragged input, or LIPASR_MFCC_FUSED=1): y stays in LDS
                 "note": "stage is fp32-compute-bound (8.7 MFLOP/utt vs 67.5 kB/utt): see DESIGN.md"}
     if ex.get("mfcc_cus"):
         # the pipeline confines the MFCC stream to a share of the CUs (DESIGN.md, step level): its kernels take longer by
@@ -374,6 +412,14 @@ def main():
         out["reference_config_2_pre_extracted_f32"] = _short(["--pre-extracted"], batch, k, w)
         out["reference_config_2_pre_extracted_bf16"] = _short(["--pre-extracted", "--bf16"], batch, k, w)
         out["reference_config_5_pgd20_1gpu"] = _short(["--pgd", "20", "--pgd-eps", "0.5"], batch, min(k, 20), min(w, 5))
+        try:  # the Keras-shaped fit() entry with the constraint as a callback, as train_constraints.py drives it
+            import subprocess
+
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", "1", "--fit-api"], capture_output=True, text=True, timeout=300,
+                               env=dict(os.environ, WORLD_SIZE="1", RANK="0"))
+            out["reference_fit_api_batch_512"] = dict(json.loads(r.stdout.strip().splitlines()[-1]), measured_in="child process")
+        except Exception as e:
+            out["reference_fit_api_batch_512"] = {"error": f"{type(e).__name__}: {e}"[:200]}
         pool = None
     if world == 1 and not args.skip_cpu_baseline:
         pool = None
