@@ -16,6 +16,7 @@
 //                          major layout, optional fused StandardScaler affine.
 #include "common.h"
 #include "mfcc_tables.h"
+#include <type_traits>
 
 namespace lipasr {
 
@@ -74,6 +75,15 @@ void mfcc_plan_free(MfccPlan* p) {
     if (q) (void)hipFree(q);
   for (hipEvent_t e : p->prof_events) (void)hipEventDestroy(e);
   delete p;
+}
+
+// per-clip lengths, the expressions of tables::resampled_lengths (librosa.load -> resampy int(n ratio), fix_length ceil)
+__device__ __forceinline__ void clip_lengths(int n, int sr_in, int* n_vy, int* n_y, int* n_frames) {
+  const double r = (double)kSr / (double)sr_in;
+  const double v = (double)n * r;
+  *n_vy = (int)v;
+  *n_y = (int)ceil(v);
+  *n_frames = (*n_y >= 2) ? 1 + *n_y / kHop : 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -371,8 +381,10 @@ typedef _Float16 rs_h4 __attribute__((ext_vector_type(4)));
 constexpr int kRhK = 160, kRhChunks = kRhK / 16, kRhRowHalfs = 480, kRhRowBytes = 2 * kRhRowHalfs * 2 + 16;
 constexpr float kRhTapScale = 64.0f, kRhSigScale = 2048.0f;
 
+// I16: int16 PCM in (float32 otherwise).  RAGGED: nv[] holds a length per clip (else every row is n_samp long and nv is not read).
+template <bool I16, bool RAGGED>
 __global__ __launch_bounds__(64 * kRpMaxWaves) __attribute__((amdgpu_waves_per_eu(4, 4)))
-void resample_persist_h2_kernel(const float* __restrict__ x, int n_samp, int batch, float* __restrict__ y, int n_valid, int n_y,
+void resample_persist_h2_kernel(const void* __restrict__ xv, const int* __restrict__ nv, int sr_in, int n_samp, int batch, float* __restrict__ y, int n_valid, int n_y,
                                 int up, int down, int left, int nq, int n_tiles, const uint4* __restrict__ HbandH,
                                 const int* __restrict__ lo, int n_ptiles_rt, int dbg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char xh[];  // [2][32][kRhRowBytes]
@@ -400,44 +412,83 @@ void resample_persist_h2_kernel(const float* __restrict__ x, int n_samp, int bat
     }
   }
   const int band0 = mm ? ((lo[wave] + 1) & ~7) : 0;  // first sample of the band in the window, a multiple of 8
-  float4 stage[kFillMax];
-  // Fill mapping without divisions: 32 threads per window row (1024 threads = 32 rows), thread (row, c) moves the float4
-  // columns c, c + 32, c + 64, c + 96 of its row (120 of the 128 exist): 512 contiguous bytes per row and instruction.
-  const int frow = tid >> 5, fcol = tid & 31;
+  // what a fill holds between its loads and its LDS stores: float4, or the four int16 samples as they came
+  using stage_t = typename std::conditional<I16, short4, float4>::type;
+  stage_t stage[kFillMax];
+  // Fill mapping without divisions: a wavefront moves two window rows (16 wavefronts, 32 rows), lane l the 4-sample columns l and
+  // l + 64 of each (120 of the 128 exist): 1 KB contiguous per load instruction (fp32), 512 B per LDS store, and the length of
+  // the row's clip is wave-uniform -- it stays in a scalar register (this kernel has no vector register to spare: the tap
+  // fragments alone take 80 of its 128).
+  const int r0 = u0 + 2 * wave;
+  const int n_clip0 = __builtin_amdgcn_readfirstlane((r0 < batch) ? (RAGGED ? min(max(nv[r0], 0), n_samp) : n_samp) : 0);
+  const int n_clip1 = __builtin_amdgcn_readfirstlane((r0 + 1 < batch) ? (RAGGED ? min(max(nv[r0 + 1], 0), n_samp) : n_samp) : 0);
+  // outputs from int(n ratio) on are zeros (fix_length).  With per-clip lengths that is at most ONE sample per clip that anyone
+  // reads (ceil(n ratio) - int(n ratio) <= 1) and stft_mel2_kernel, which knows the clip's length, takes it as zero itself
+  const int t_lim = RAGGED ? n_y : n_valid;
   auto fetch = [&](int q) {
-    const int base = down * q - left;
-    const int u = u0 + frow;
-    const float* src = x + (size_t)u * n_samp + base;
+    const int base = down * q - left;  // a multiple of 4, as n_samp is
+    const stage_t* src = static_cast<const stage_t*>(xv) + (((long)r0 * n_samp + base) >> 2) + lane;
 #pragma unroll
     for (int j = 0; j < kFillMax; ++j) {
-      const int v = fcol + 32 * j, n = base + 4 * v;
-      stage[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (v < kVecPerRow && u < batch && n >= 0 && n + 3 < n_samp) stage[j] = *reinterpret_cast<const float4*>(src + 4 * v);
+      const int v = lane + 64 * (j & 1), n = base + 4 * v;
+      const int n_clip = (j >> 1) ? n_clip1 : n_clip0;
+      stage[j] = stage_t{};
+      // (n + 3 < n_samp: n and n_samp are multiples of 4; a clip that ends inside the four is cut in deposit)
+      if (v < kVecPerRow && n >= 0 && n < n_clip) stage[j] = src[(j >> 1) * (n_samp >> 2) + 64 * (j & 1)];
     }
   };
-  auto deposit = [&](unsigned char* xs) {
-    unsigned char* drow = xs + frow * kRhRowBytes + 8 * fcol;
+  auto deposit = [&](unsigned char* xs, int q) {
+    unsigned char* drow = xs + 2 * wave * kRhRowBytes + 8 * lane;
+    // a clip that ends inside a group of four: what follows in the row is not the clip's.  Cut under a scalar branch (rare; no
+    // select on the path below, where every register is taken -- as it is, this code costs the RAGGED instances two spilled
+    // tap fragments, reloaded per q-block)
+#pragma unroll
+    for (int r = 0; RAGGED && r < 2; ++r) {
+      const int rel = (r ? n_clip1 : n_clip0) - (down * q - left);  // samples of the clip in this window (wave-uniform)
+      if ((rel & 3) != 0 && rel > 0 && rel < 4 * kVecPerRow) {
+        const int g = rel >> 2, cr = rel & 3;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          if (lane + 64 * jj == g) {
+            stage_t& t = stage[2 * r + jj];
+            if (cr <= 1) t.y = 0;
+            if (cr <= 2) t.z = 0;
+            t.w = 0;
+          }
+        }
+      }
+    }
 #pragma unroll
     for (int j = 0; j < kFillMax; ++j) {
-      if (fcol + 32 * j < kVecPerRow) {
-        const float e[4] = {stage[j].x, stage[j].y, stage[j].z, stage[j].w};
+      if (lane + 64 * (j & 1) < kVecPerRow) {
+        float e[4];
+        if constexpr (I16) {
+          const short4 sv = stage[j];
+          e[0] = (float)sv.x * (kRhSigScale / 32768.0f); e[1] = (float)sv.y * (kRhSigScale / 32768.0f);
+          e[2] = (float)sv.z * (kRhSigScale / 32768.0f); e[3] = (float)sv.w * (kRhSigScale / 32768.0f);
+        } else {
+          const float4 fv = stage[j];
+          e[0] = fv.x * kRhSigScale; e[1] = fv.y * kRhSigScale; e[2] = fv.z * kRhSigScale; e[3] = fv.w * kRhSigScale;
+        }
         rs_h4 hi, lw;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          const float sc = fminf(fmaxf(e[c] * kRhSigScale, -65000.0f), 65000.0f);
+          const float sc = fminf(fmaxf(e[c], -65000.0f), 65000.0f);
           const _Float16 a = (_Float16)sc;
           hi[c] = a;
           lw[c] = (_Float16)(sc - (float)a);
         }
-        unsigned char* d = drow + 256 * j;
+        unsigned char* d = drow + (j >> 1) * kRhRowBytes + 512 * (j & 1);
         *reinterpret_cast<rs_h4*>(d) = hi;
         *reinterpret_cast<rs_h4*>(d + 2 * kRhRowHalfs) = lw;
+        // a clip that ends inside this group of four: what follows in the row is not the clip's.  Zeroed after the fact, by
+        // the lane that wrote it (rare, and no select on the main path)
       }
     }
   };
   if (q_begin < q_end) {
     fetch(q_begin);
-    deposit(xh);
+    deposit(xh, q_begin);
   }
   __syncthreads();
   int cur = 0;
@@ -467,10 +518,10 @@ void resample_persist_h2_kernel(const float* __restrict__ x, int n_samp, int bat
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int row = (e & 3) + 8 * (e >> 2);
-        if (u0 + row + 4 * h < batch) yb[off + row * n_y] = t < n_valid ? acc[e] * (1.0f / (kRhTapScale * kRhSigScale)) : 0.0f;
+        if (u0 + row + 4 * h < batch) yb[off + row * n_y] = t < t_lim ? acc[e] * (1.0f / (kRhTapScale * kRhSigScale)) : 0.0f;
       }
     }
-    if (more) deposit(xh + (cur ^ 1) * 32 * kRhRowBytes);
+    if (more) deposit(xh + (cur ^ 1) * 32 * kRhRowBytes, q + 1);
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
     __builtin_amdgcn_s_barrier();
     cur ^= 1;
@@ -603,6 +654,10 @@ struct StftArgs {
   float* db;    // [B][n_frames][128]
   float* fmax;  // [B][n_frames]
   int stage_mask;  // profiling only: bit0 skip the FFT passes, bit1 skip the mel reduction (results are wrong)
+  // clips of different lengths in one launch (stft_mel2_kernel): samples per clip, or null; n_y / n_frames above are then the
+  // longest clip's (the strides of y, db, fmax) and every clip uses its own
+  const int* n_valid;
+  int sr_in, n_samp_max;
 };
 
 constexpr int kTPair = 1028;    // stride of the two float2 (frame 0, frame 1) weighted-power arrays, >= 1025 bins
@@ -816,7 +871,7 @@ __device__ __forceinline__ void lds_barrier2() {
 // m = tid & 127) holds the dB values of mel bin m for frames f0 + 2 pr (dbe) and f0 + 2 pr + 1 (dbo), which it has also
 // stored to a.db.  buf / rsum: the workgroup's LDS; every barrier inside is an LDS-only barrier.
 __device__ __forceinline__ void stft2_quad(const StftArgs& a, float4* __restrict__ buf, float4 (*__restrict__ rsum)[128],
-                                           const float* __restrict__ yu, int u, int f0, int tid, float& dbe, float& dbo) {
+                                           const float* __restrict__ yu, int u, int f0, int tid, int n_vy, int n_y, int n_frames, float& dbe, float& dbo) {
   const int lane = tid & 63;
   // per-thread constants (L2-resident tables), on their way before the sample loads
   const int mel_part = (tid >> 6) & 1, mel_run = ((tid >> 7) << 6) + lane;
@@ -830,7 +885,7 @@ __device__ __forceinline__ void stft2_quad(const StftArgs& a, float4* __restrict
   load_tw<8>(a.tw, tid, 8, w2);
   load_tw<8>(a.tw, tid, 64, w3);
   cp2 x0[8];
-  if (f0 >= 2 && f0 + 3 < a.n_frames && (f0 + 3) * 512 + 1024 <= a.n_y) {
+  if (f0 >= 2 && f0 + 3 < n_frames && (f0 + 3) * 512 + 1024 <= n_vy) {
     // all four frames inside the clip: frame j is frame 0 moved by 2 j of the thread's 256-sample steps
     const float* p = yu + (f0 * 512 - 1024) + tid;
     float sm[14];
@@ -841,13 +896,16 @@ __device__ __forceinline__ void stft2_quad(const StftArgs& a, float4* __restrict
   } else {
     // edge quads (2 of a 1-s clip's 11): the generic np.pad index costs a division per sample -- a quarter of the kernel's
     // average instruction count when every edge quad paid it; clips longer than the padding reflect once
-    if (a.n_y > kNFft) {  // workgroup-uniform
+    if (n_y > kNFft) {  // workgroup-uniform
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int j0 = f0 * 512 + tid + 256 * e - 1024;
         float sj[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) sj[j] = (f0 + j < a.n_frames) ? yu[reflect_once(j0 + 512 * j, a.n_y)] : 0.0f;
+        for (int j = 0; j < 4; ++j) {
+            const int k = reflect_once(j0 + 512 * j, n_y);
+            sj[j] = (f0 + j < n_frames && k < n_vy) ? yu[k] : 0.0f;  // [n_vy, n_y): fix_length's zeros
+          }
         x0[e] = {v2f{hw[e] * sj[0], hw[e] * sj[2]}, v2f{hw[e] * sj[1], hw[e] * sj[3]}};
       }
     } else {
@@ -856,7 +914,10 @@ __device__ __forceinline__ void stft2_quad(const StftArgs& a, float4* __restrict
         const int j0 = f0 * 512 + tid + 256 * e - 1024;
         float sj[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) sj[j] = (f0 + j < a.n_frames) ? yu[reflect_index(j0 + 512 * j, a.n_y)] : 0.0f;
+        for (int j = 0; j < 4; ++j) {
+            const int k = reflect_index(j0 + 512 * j, n_y);
+            sj[j] = (f0 + j < n_frames && k < n_vy) ? yu[k] : 0.0f;
+          }
         x0[e] = {v2f{hw[e] * sj[0], hw[e] * sj[2]}, v2f{hw[e] * sj[1], hw[e] * sj[3]}};
       }
     }
@@ -983,8 +1044,8 @@ __device__ __forceinline__ void stft2_quad(const StftArgs& a, float4* __restrict
   dbe = 10.0f * log10f(fmaxf(1e-10f, se));
   dbo = 10.0f * log10f(fmaxf(1e-10f, so));
   const int fe = f0 + 2 * pr, fo = fe + 1;
-  if (fe < a.n_frames) a.db[((size_t)u * a.n_frames + fe) * 128 + m] = dbe;
-  if (fo < a.n_frames) a.db[((size_t)u * a.n_frames + fo) * 128 + m] = dbo;
+  if (fe < n_frames) a.db[((size_t)u * a.n_frames + fe) * 128 + m] = dbe;
+  if (fo < n_frames) a.db[((size_t)u * a.n_frames + fo) * 128 + m] = dbo;
 }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void stft_mel2_kernel(StftArgs a) {
@@ -1008,14 +1069,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   }
   const int f0 = 4 * fq;
   const float* yu = a.y + (size_t)u * a.n_y;
+  int n_y = a.n_y, n_frames = a.n_frames, n_vy = a.n_y;  // (one length for all: y already ends in its zeros)
+  if (a.n_valid) {  // this clip's own length: frame count and reflect padding follow it
+    clip_lengths(min(max(a.n_valid[u], 0), a.n_samp_max), a.sr_in, &n_vy, &n_y, &n_frames);
+    n_frames = min(n_frames, a.n_frames);
+  }
+  if (f0 >= n_frames) return;  // (workgroup-uniform, before any barrier)
   float dbe, dbo;
-  stft2_quad(a, buf, rsum, yu, u, f0, tid, dbe, dbo);
+  stft2_quad(a, buf, rsum, yu, u, f0, tid, n_vy, n_y, n_frames, dbe, dbo);
   const float me = wave_max(dbe), mo = wave_max(dbo);
   if (lane == 0) { wmax[tid >> 6][0] = me; wmax[tid >> 6][1] = mo; }
   lds_barrier2();
   if (tid < 4) {
     const int f = f0 + tid, w0 = 2 * (tid >> 1), c = tid & 1;
-    if (f < a.n_frames) a.fmax[(size_t)u * a.n_frames + f] = fmaxf(wmax[w0][c], wmax[w0 + 1][c]);
+    if (f < n_frames) a.fmax[(size_t)u * a.n_frames + f] = fmaxf(wmax[w0][c], wmax[w0 + 1][c]);
   }
 }
 #undef LP_F2_PASS8
@@ -1193,15 +1260,6 @@ struct FusedArgs {
   int n_groups;
   StftArgs st;         // n_y / n_frames of the LONGEST clip: strides of db / fmax
 };
-
-// per-clip lengths, the expressions of tables::resampled_lengths (librosa.load -> resampy int(n ratio), fix_length ceil)
-__device__ __forceinline__ void clip_lengths(int n, int sr_in, int* n_vy, int* n_y, int* n_frames) {
-  const double r = (double)kSr / (double)sr_in;
-  const double v = (double)n * r;
-  *n_vy = (int)v;
-  *n_y = (int)ceil(v);
-  *n_frames = (*n_y >= 2) ? 1 + *n_y / kHop : 0;
-}
 
 // one Stockham pass with the butterfly's twiddles already in registers (w[r-1] = w^r)
 template <int R>
@@ -1706,7 +1764,43 @@ static int upload(T** dptr, const std::vector<T>& v) {
   return LIPASR_OK;
 }
 
-static int launch_resample(const MfccPlan* p, const float* wav, int batch, float* y, hipStream_t st) {
+// the fp16-plane persistent resampler is the one that takes int16 PCM and per-clip lengths
+static bool resample_h2_ok(const MfccPlan* p, const void* wav, int fmt) {
+  const uintptr_t addr = reinterpret_cast<uintptr_t>(wav);
+  const bool vec4 = ((p->n_samp & 3) == 0) && ((p->down & 3) == 0) && ((addr & (fmt ? 7 : 15)) == 0);
+  const int n_waves = p->n_ptiles;
+  return !p->identity && p->d_hband && p->d_hbandh && !(p->stage_mask & (4 | 16)) && vec4 && n_waves >= 8 && n_waves <= kRpMaxWaves &&
+         32 * ((kRsStride - 1) / 4) <= 5 * 64 * n_waves && p->left == 64 && p->down + 128 + 32 <= kRhRowHalfs;
+}
+
+static int launch_resample(const MfccPlan* p, const void* wav_any, int fmt, const int* n_valid, int batch, float* y, hipStream_t st) {
+  if (resample_h2_ok(p, wav_any, fmt)) {
+    const int nq = (p->n_y + p->up - 1) / p->up, tiles = (batch + 31) / 32;
+    int wgs = p->rs_target_wgs;  // one workgroup per CU this stream may use
+    if (wgs < tiles) wgs = tiles;
+    if (wgs > tiles * nq) wgs = tiles * nq;
+    const size_t ldsh = (size_t)2 * 32 * kRhRowBytes;
+    using kern_t = void (*)(const void*, const int*, int, int, int, float*, int, int, int, int, int, int, int, const uint4*, const int*, int, int);
+    static const kern_t kerns[4] = {resample_persist_h2_kernel<false, false>, resample_persist_h2_kernel<true, false>,
+                                    resample_persist_h2_kernel<false, true>, resample_persist_h2_kernel<true, true>};
+    static bool attr_h = false;
+    if (!attr_h) {
+      for (kern_t k : kerns)
+        LP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsh));
+      attr_h = true;
+    }
+    hipLaunchKernelGGL(kerns[(fmt ? 1 : 0) + (n_valid ? 2 : 0)], dim3(wgs), dim3(64 * kRpMaxWaves), ldsh, st, wav_any, n_valid,
+                       p->sr_in, p->n_samp, batch, y, p->n_valid, p->n_y, p->up, p->down, p->left, nq, tiles,
+                       reinterpret_cast<const uint4*>(p->d_hbandh), p->d_lo, p->n_ptiles, (p->stage_mask >> 16) & 7);
+    LP_LAUNCH_CHECK();
+    return LIPASR_OK;
+  }
+  if (fmt != 0 || n_valid) {
+    set_error("lipasr_mfcc: int16 input and per-clip lengths need the fp16-plane resampler (a rational ratio with <= 16 phase tiles, "
+              "row length a multiple of 4); this plan is %d Hz with rows of %d", p->sr_in, p->n_samp);
+    return LIPASR_EUNSUPPORTED;
+  }
+  const float* wav = static_cast<const float*>(wav_any);
   if (p->identity) {
     hipLaunchKernelGGL(copy_pad_kernel, dim3(32, batch), dim3(256), 0, st, wav, p->n_samp, y, p->n_y);
     LP_LAUNCH_CHECK();
@@ -1715,9 +1809,9 @@ static int launch_resample(const MfccPlan* p, const float* wav, int batch, float
   const int nq = (p->n_y + p->up - 1) / p->up;
   const bool vec4 = ((p->n_samp & 3) == 0) && ((p->down & 3) == 0) && ((reinterpret_cast<uintptr_t>(wav) & 15) == 0);
   const int n_waves = p->n_ptiles;
-  if (p->d_hband && !(p->stage_mask & (4 | 64)) && vec4 && n_waves >= 8 && n_waves <= kRpMaxWaves &&
+  if (p->d_hband && !(p->stage_mask & 4) && vec4 && n_waves >= 8 && n_waves <= kRpMaxWaves &&
       32 * ((kRsStride - 1) / 4) <= 5 * 64 * n_waves) {
-    // persistent form: one workgroup per CU-sized share of the work
+    // persistent fp32 form (the parity reference of the fp16-plane kernel): one workgroup per CU-sized share of the work
     const size_t lds = (size_t)2 * 32 * kRsStride * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
@@ -1726,22 +1820,9 @@ static int launch_resample(const MfccPlan* p, const float* wav, int batch, float
       attr_set = true;
     }
     const int tiles = (batch + 31) / 32;
-    int wgs = p->rs_target_wgs;  // one workgroup per CU this stream may use
+    int wgs = p->rs_target_wgs;
     if (wgs < tiles) wgs = tiles;
     if (wgs > tiles * nq) wgs = tiles * nq;
-    if (p->d_hbandh && !(p->stage_mask & 16) && p->left == 64 && p->down + 128 + 32 <= kRhRowHalfs) {
-      const size_t ldsh = (size_t)2 * 32 * kRhRowBytes;
-      static bool attr_h = false;
-      if (!attr_h) {
-        LP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(resample_persist_h2_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsh));
-        attr_h = true;
-      }
-      hipLaunchKernelGGL(resample_persist_h2_kernel, dim3(wgs), dim3(64 * kRpMaxWaves), ldsh, st, wav, p->n_samp, batch, y,
-                         p->n_valid, p->n_y, p->up, p->down, p->left, nq, tiles, reinterpret_cast<const uint4*>(p->d_hbandh), p->d_lo, n_waves, (p->stage_mask >> 16) & 7);
-      LP_LAUNCH_CHECK();
-      return LIPASR_OK;
-    }
     hipLaunchKernelGGL(resample_persist_kernel, dim3(wgs), dim3(64 * n_waves), lds, st, wav, p->n_samp, batch, y,
                        p->n_valid, p->n_y, p->up, p->down, p->left, nq, tiles, p->d_hband, p->d_lo);
   } else if (p->d_hband && !(p->stage_mask & 4)) {
@@ -1782,6 +1863,7 @@ static void fill_stft_args(const MfccPlan* p, const float* y, StftArgs* a) {
   a->mel_wlo = p->d_mel_wlo; a->mel_whi = p->d_mel_whi; a->mel_start = p->d_mel_pstart; a->mel_len = p->d_mel_plen;
   a->db = p->d_db; a->fmax = p->d_fmax;
   a->stage_mask = p->stage_mask;
+  a->n_valid = nullptr; a->sr_in = p->sr_in; a->n_samp_max = p->n_samp;
 }
 
 // stages 1 + 2 in one kernel (mfcc_fused_kernel); wav: float32 (fmt 0) or int16 PCM (fmt 1)
@@ -1807,14 +1889,17 @@ static int launch_fused(const MfccPlan* p, const void* wav, int fmt, const int* 
   return LIPASR_OK;
 }
 
-static int launch_from_22k(const MfccPlan* p, const float* y, int batch, int L, const double* am, const double* as,
+static bool stft2_ok(const MfccPlan* p) { return !p->dft && !(p->stage_mask & (64 | 3)); }
+
+static int launch_from_22k(const MfccPlan* p, const float* y, const int* n_valid, int batch, int L, const double* am, const double* as,
                            float* out, hipStream_t st, hipEvent_t mid = nullptr) {  // mid: recorded between stft_mel and dct
   StftArgs a;
-  a.y = y; a.n_y = p->n_y; a.n_frames = p->n_frames; a.hann = p->d_hann;
-  a.tw = reinterpret_cast<const float2*>(p->d_tw);
-  a.mel_wlo = p->d_mel_wlo; a.mel_whi = p->d_mel_whi; a.mel_start = p->d_mel_pstart; a.mel_len = p->d_mel_plen;
-  a.db = p->d_db; a.fmax = p->d_fmax;
-  a.stage_mask = p->stage_mask;
+  fill_stft_args(p, y, &a);
+  a.n_valid = n_valid; a.sr_in = p->sr_in; a.n_samp_max = p->n_samp;
+  if (n_valid && !stft2_ok(p)) {
+    set_error("lipasr_mfcc: per-clip lengths need the 2048/512 STFT kernel; this plan has n_fft %d", p->n_fft);
+    return LIPASR_EUNSUPPORTED;
+  }
   if (p->dft) {
     DftArgs d;
     d.y = y; d.n_y = p->n_y; d.batch = batch; d.table = p->d_dft; d.hop = p->hop; d.n_fft = p->n_fft; d.k_rows = p->dft_krows; d.n_tiles = p->dft_tiles;
@@ -1827,14 +1912,14 @@ static int launch_from_22k(const MfccPlan* p, const float* y, int batch, int L, 
       LP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dft_mel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)dl));
     hipLaunchKernelGGL(dft_mel_kernel, dim3((d.total_rows + kDftRows - 1) / kDftRows), dim3(64 * p->dft_tiles), dl, st, d);
-  } else if (!(p->stage_mask & (64 | 3))) {
+  } else if (stft2_ok(p)) {
     hipLaunchKernelGGL(stft_mel2_kernel, dim3((p->n_frames + 3) / 4, batch), dim3(256), 0, st, a);
   } else {
     hipLaunchKernelGGL(stft_mel_kernel, dim3((p->n_frames + 1) / 2, batch), dim3(256), 0, st, a);
   }
   LP_LAUNCH_CHECK();
   if (mid) LP_HIP(hipEventRecord(mid, st));
-  return launch_dct(p, batch, L, am, as, out, nullptr, st);
+  return launch_dct(p, batch, L, am, as, out, n_valid, st);
 }
 
 }  // namespace lipasr
@@ -1969,7 +2054,7 @@ static int plan_check(const char* fn, const MfccPlan* p, int batch, int L) {
 static int plan_resample(MfccPlan* p, const float* wav, int batch, float* y, hipStream_t st) {
   hipEvent_t* ev = (p->prof_n < p->prof_cap) ? &p->prof_events[5 * (size_t)p->prof_n] : nullptr;
   if (ev) LP_HIP(hipEventRecord(ev[0], st));
-  int rc = launch_resample(p, wav, batch, y, st);
+  int rc = launch_resample(p, wav, 0, nullptr, batch, y, st);
   if (rc != LIPASR_OK) return rc;
   if (ev) {
     LP_HIP(hipEventRecord(ev[1], st));
@@ -1985,7 +2070,7 @@ static int plan_from_22k(MfccPlan* p, const float* y, int batch, int n_y, int L,
   // timed only as the second half of a split extraction (a resample timing is already in the slot)
   hipEvent_t* ev = (p->prof_half && p->prof_n < p->prof_cap) ? &p->prof_events[5 * (size_t)p->prof_n] : nullptr;
   if (ev) LP_HIP(hipEventRecord(ev[2], st));
-  int rc = launch_from_22k(p, y, batch, L, am, as, out, st, ev ? ev[3] : nullptr);
+  int rc = launch_from_22k(p, y, nullptr, batch, L, am, as, out, st, ev ? ev[3] : nullptr);
   if (rc != LIPASR_OK) return rc;
   if (ev) {
     LP_HIP(hipEventRecord(ev[4], st));
@@ -2001,11 +2086,15 @@ static int plan_run(MfccPlan* p, const void* wav, int fmt, const int* n_valid, i
   LP_CHECK_ARG(wav && out, "lipasr_mfcc: null argument");
   LP_CHECK_ARG(fmt == 0 || fmt == 1, "lipasr_mfcc: sample format %d (0 = float32, 1 = int16 PCM)", fmt);
   LP_CHECK_ARG((am == nullptr) == (as == nullptr), "lipasr_mfcc: give both affine arrays or neither");
+  // three kernels (resample -> y in HBM -> STFT+mel -> DCT) unless the plan prefers the single fused resample+STFT kernel, which
+  // moves 2.6x fewer bytes and is slower; the fused kernel also takes over when the three-kernel form cannot read
+  // this input (unaligned int16 / ragged rows)
   const bool can_fuse = p->fused && !(p->stage_mask & 128);
-  const bool fused = can_fuse && (p->prefer_fused || fmt != 0 || n_valid != nullptr);
-  if (!can_fuse && (fmt != 0 || n_valid)) {
-    set_error("lipasr_mfcc: int16 input and per-clip lengths need the fused 2048/512 path (16 kHz or 8 kHz input); this plan is %d Hz, n_fft %d",
-              p->sr_in, p->n_fft);
+  const bool three_ok = (fmt == 0 && !n_valid) || (resample_h2_ok(p, wav, fmt) && stft2_ok(p));
+  const bool fused = can_fuse && (p->prefer_fused || !three_ok);
+  if (!fused && !three_ok) {
+    set_error("lipasr_mfcc: int16 input and per-clip lengths need the 2048/512 path with a 441/320- or 441/160-style resampler "
+              "(16 kHz or 8 kHz input, rows a multiple of 4 samples); this plan is %d Hz, n_fft %d, rows of %d", p->sr_in, p->n_fft, p->n_samp);
     return LIPASR_EUNSUPPORTED;
   }
   hipEvent_t* ev = (!p->prof_half && p->prof_n < p->prof_cap) ? &p->prof_events[5 * (size_t)p->prof_n] : nullptr;
@@ -2021,12 +2110,12 @@ static int plan_run(MfccPlan* p, const void* wav, int fmt, const int* n_valid, i
     if ((rc = launch_dct(p, batch, L, am, as, out, n_valid, st)) != LIPASR_OK) return rc;
   } else {
     if (ev) LP_HIP(hipEventRecord(ev[0], st));
-    if ((rc = launch_resample(p, static_cast<const float*>(wav), batch, p->d_y, st)) != LIPASR_OK) return rc;
+    if ((rc = launch_resample(p, wav, fmt, n_valid, batch, p->d_y, st)) != LIPASR_OK) return rc;
     if (ev) {
       LP_HIP(hipEventRecord(ev[1], st));
       LP_HIP(hipEventRecord(ev[2], st));
     }
-    if ((rc = launch_from_22k(p, p->d_y, batch, L, am, as, out, st, ev ? ev[3] : nullptr)) != LIPASR_OK) return rc;
+    if ((rc = launch_from_22k(p, p->d_y, n_valid, batch, L, am, as, out, st, ev ? ev[3] : nullptr)) != LIPASR_OK) return rc;
   }
   if (ev) {
     LP_HIP(hipEventRecord(ev[4], st));

@@ -54,7 +54,8 @@ class MfccExtractor:
 
     def set(self, key, value):
         """lipasr_mfcc_plan_set: key 0 = stage mask (64 = round-2 STFT kernel, 128 = never fuse), key 1 = resampler workgroups,
-        key 2 = 1: the fused resample -> STFT kernel for every batch (default: only for int16 / ragged input)."""
+        key 2 = 1: the fused resample -> STFT kernel for every batch (default: only where the three kernels cannot read the
+        input: int16 / ragged rows that are not a multiple of 4 samples long)."""
         N.check(N.lib.lipasr_mfcc_plan_set(self._plan, int(key), int(value)))
 
     def profile_begin(self, max_calls):
@@ -174,7 +175,7 @@ def compute_mfcc_all_files(filenames, chunk=512):
         x, sr = read_wav(fn, pcm16=True)
         by_sr.setdefault((sr, x.dtype == np.int16), []).append((i, x))
     for (sr, is_pcm), items in by_sr.items():
-        ragged_ok = sr in (16000, 8000)  # the fused kernel's rates; other rates: one launch per distinct length
+        ragged_ok = sr in (16000, 8000)  # the rates whose plans take per-clip lengths; other rates: one launch per distinct length
         if ragged_ok:
             batches = [items[s:s + chunk] for s in range(0, len(items), chunk)]
         else:

@@ -338,8 +338,10 @@ int lipasr_mfcc_from_22k(lipasr_handle_t h, const float* y, int batch, int n_y, 
  * the samples of each row that belong to the clip.  Clip u is processed exactly as a plan of
  * n_valid[u] samples would process it alone (resampled length, frame count, reflect padding and the
  * top_db maximum follow its own length; frames past its end are the zero columns of :33-37).  Same
- * bits as lipasr_mfcc_f32 on pcm * 2^-15.  Needs the fused 2048/512 path (16 kHz / 8 kHz input);
- * otherwise LIPASR_EUNSUPPORTED. */
+ * bits as lipasr_mfcc_f32 on pcm * 2^-15.  Needs the 2048/512 path with the 441/320 or 441/160 resampler
+ * (16 kHz / 8 kHz input); otherwise LIPASR_EUNSUPPORTED.  Rows whose length is a multiple of 4 samples go
+ * through the same three kernels as float32 batches (the resampler reads int16 and cuts each row at its
+ * clip's end); other row lengths through the fused resample -> STFT kernel. */
 int lipasr_mfcc_i16(lipasr_handle_t h, const int16_t* pcm, const int* n_valid, int batch,
                     int utterance_length, const double* affine_mean, const double* affine_scale,
                     float* out, lipasr_stream_t stream);
@@ -371,8 +373,9 @@ int lipasr_mfcc_profile_end(lipasr_handle_t h, float* avg_ms3, int* n_calls);
 int lipasr_mfcc_plan_profile_begin(lipasr_mfcc_t p, int max_calls);
 int lipasr_mfcc_plan_profile_end(lipasr_mfcc_t p, float* avg_ms3, int* n_calls);
 /* knobs of one plan: keys 0 and 1 as lipasr_debug_set; key 2: value != 0 makes the plan run the fused resample -> STFT
- * kernel for every batch (1.9x the algorithmic HBM bytes instead of 4.5x, but about 1.5x the time of the three-kernel path
- * on a whole MI355X: DESIGN.md section 3); by default the fused kernel runs only where it is needed (int16 input, n_valid). */
+ * kernel for every batch (1.7x the algorithmic HBM bytes instead of 4.6x, but about 1.7x the time of the three-kernel path
+ * on a whole MI355X: DESIGN.md section 3); by default the fused kernel runs only where the three-kernel path cannot read
+ * the input (int16 or per-clip lengths in rows that are not a multiple of 4 samples long). */
 int lipasr_mfcc_plan_set(lipasr_mfcc_t p, int key, int value);
 
 /* A12 audio-domain noise on device, Philox RNG (attacks.py:73-86, 145-183, 222-245), in place on

@@ -188,40 +188,51 @@ def test_fused_kernel_other_rates_and_lengths(cuda, sr_in, n):
 
 def test_int16_pcm_input_is_bit_identical(cuda):
     """lipasr_mfcc_i16 / sample_format 1: the device scales by 2^-15 while staging, which is exactly the host conversion
-    (extract_features_construct_dataset.py:27, librosa.load's decode of 16-bit PCM)."""
+    (extract_features_construct_dataset.py:27, librosa.load's decode of 16-bit PCM).  Both forms of the path: the three
+    kernels (the resampler reads int16 directly) and the fused resample+STFT kernel."""
     from lipasr.extract_features_construct_dataset import MfccExtractor
     from lipasr.synth import synth_clips
 
     waves, _ = synth_clips(19, seed=3)
     pcm = np.clip(np.round(waves * 32768.0), -32768, 32767).astype(np.int16)
+    ref = M.compute_mfcc_batch(pcm.astype(np.float32) / 32768.0)
     ex = MfccExtractor(16000, 16000, 32)
-    ex.set(2, 1)  # float32 batches through the fused kernel as well (int16 always takes it)
-    a = ex(torch.as_tensor(pcm).cuda())
-    b = ex(dev(pcm.astype(np.float32) / 32768.0))
-    assert torch.equal(a, b)
-    assert np.abs(a.cpu().numpy() - M.compute_mfcc_batch(pcm.astype(np.float32) / 32768.0)).max() < ATOL
-    # an unaligned row length (no vector loads) and the handle-level C entry point
+    res = {}
+    for fused in (0, 1):
+        ex.set(2, fused)
+        a = ex(torch.as_tensor(pcm).cuda())
+        b = ex(dev(pcm.astype(np.float32) / 32768.0))
+        assert torch.equal(a, b), fused
+        assert np.abs(a.cpu().numpy() - ref).max() < ATOL
+        res[fused] = a
+    assert (res[0] - res[1]).abs().max() < 1e-3  # two kernels, one algorithm (fp16-plane vs fp32 resampling, other twiddles)
+    # a row length that is not a multiple of 4 (no vector loads: the plan falls back to the fused kernel by itself) and the
+    # handle-level C entry point
     import ctypes as C
 
     from lipasr import _native as N
 
     odd = pcm[:, :15999].copy()
     exo = MfccExtractor(16000, 15999, 32)
+    oi, of = exo(torch.as_tensor(odd).cuda()), exo(dev(odd.astype(np.float32) / 32768.0))  # fused kernel | fp32 three-kernel path
+    assert (oi - of).abs().max() < 1e-3
     exo.set(2, 1)
-    assert torch.equal(exo(torch.as_tensor(odd).cuda()), exo(dev(odd.astype(np.float32) / 32768.0)))
+    assert torch.equal(oi, exo(dev(odd.astype(np.float32) / 32768.0)))
     h = N.get_handle(0)
     N.check(N.lib.lipasr_mfcc_plan(h.h, 16000, 16000, 32))
-    N.check(N.lib.lipasr_debug_set(h.h, 2, 1))
     out = torch.empty(19, 880, device="cuda")
     N.check(N.lib.lipasr_mfcc_i16(h.h, N.ptr(torch.as_tensor(pcm).cuda()), None, 19, 44, None, None, N.ptr(out), N.stream_ptr()))
-    assert torch.equal(out, a)
+    assert torch.equal(out, res[0])
 
 
-def test_ragged_batch_equals_per_clip_launches(cuda):
+@pytest.mark.parametrize("fused", [0, 1])
+def test_ragged_batch_equals_per_clip_launches(cuda, fused):
     """Clips of different lengths in ONE launch (compute_mfcc_all_files loops files of any length,
     extract_features_construct_dataset.py:144-150): clip u with n_valid[u] samples comes out exactly as a plan made
     for that length produces it alone -- resampled length, frame count, reflect padding, the top_db maximum and the zero
-    columns past its last frame.  Garbage beyond n_valid in a row must not matter."""
+    columns past its last frame.  Garbage beyond n_valid in a row must not matter.  fused = 0: the three kernels
+    (resample_persist_h2_kernel<., true> cuts each row at its clip's end, stft_mel2_kernel takes per-clip lengths);
+    fused = 1: mfcc_fused_kernel."""
     from lipasr.extract_features_construct_dataset import MfccExtractor
     from lipasr.synth import synth_clips
 
@@ -232,37 +243,76 @@ def test_ragged_batch_equals_per_clip_launches(cuda):
     for i, n in enumerate(lens):
         padded[i, n:] = rng.standard_normal(16000 - n)  # not zeros: the tail is outside the clip
     ex = MfccExtractor(16000, 16000, 16)
+    ex.set(2, fused)
     sc_mean = torch.as_tensor(rng.standard_normal(880)).cuda()
     sc_scale = torch.as_tensor(rng.uniform(0.5, 2.0, 880)).cuda()
     got = ex(dev(padded), n_valid=torch.as_tensor(lens).cuda())
     got_aff = ex(dev(padded), 44, sc_mean, sc_scale, n_valid=torch.as_tensor(lens).cuda())
     for i, n in enumerate(lens):
         one = MfccExtractor(16000, int(n), 1)
-        one.set(2, 1)  # the same (fused) kernel as the ragged launch: bit-identical results are the claim
+        one.set(2, fused)
         alone = one(dev(waves[i:i + 1, :n]))
-        assert torch.equal(got[i:i + 1], alone), (i, n, float((got[i:i + 1] - alone).abs().max()))
-        assert torch.equal(got_aff[i:i + 1], one(dev(waves[i:i + 1, :n]), 44, sc_mean, sc_scale)), (i, n)
+        alone_aff = one(dev(waves[i:i + 1, :n]), 44, sc_mean, sc_scale)
+        # the same kernels as the ragged launch -> bit-identical.  (Three-kernel form: a row length that is not a multiple of 4
+        # sends the single-clip plan to another resampling kernel, fp32 instead of fp16 planes: same algorithm, ~1e-5 apart.)
+        if fused or n % 4 == 0:
+            assert torch.equal(got[i:i + 1], alone), (i, n, float((got[i:i + 1] - alone).abs().max()))
+            assert torch.equal(got_aff[i:i + 1], alone_aff), (i, n)
+        else:
+            assert (got[i:i + 1] - alone).abs().max() < 1e-3, (i, n, float((got[i:i + 1] - alone).abs().max()))
+            assert (got_aff[i:i + 1] - alone_aff).abs().max() < 2e-3, (i, n)
         ref = M.compute_mfcc_batch(waves[i:i + 1, :n])
         assert np.abs(got[i:i + 1].cpu().numpy() - ref).max() < ATOL, (i, n)
         one.close()
-    # int16 + ragged together, and through the module-level entry
+    # int16 + ragged together, and through the module-level entry (the default form of the path)
     from lipasr.extract_features_construct_dataset import mfcc
 
     pcm = np.clip(np.round(padded * 32768.0), -32768, 32767).astype(np.int16)
     a = mfcc(pcm, 16000, n_valid=lens)
     b = mfcc(pcm.astype(np.float32) / 32768.0, 16000, n_valid=lens)
     assert torch.equal(a, b)
+    # the ragged launch with every clip full-length is the plain launch
+    full = torch.full((12,), 16000, dtype=torch.int32, device="cuda")
+    assert torch.equal(ex(dev(waves), n_valid=full), ex(dev(waves)))
     # a zero-length row has no frame at all -> the zero columns of fix_frames; one sample resamples to ceil(1.378) = 2
     # samples = one frame, zero columns after it
     z = ex(dev(padded[:2]), n_valid=torch.as_tensor(np.array([0, 1], np.int32)).cuda()).cpu().numpy().reshape(2, 20, 44)
     assert np.count_nonzero(z[0]) == 0
     assert np.isfinite(z[1]).all() and np.count_nonzero(z[1, :, 1:]) == 0 and z[1, 0, 0] < -100.0
+    ex.close()
 
 
-def test_ragged_and_int16_need_the_fused_path(cuda):
+def test_ragged_batch_large_and_mixed(cuda):
+    """A loader-sized ragged int16 batch (random lengths, 300 clips: several 32-row tiles, tiles whose last rows are missing)
+    through the three-kernel form against the fused kernel; both cut every clip at its own end."""
+    from lipasr.extract_features_construct_dataset import MfccExtractor
+    from lipasr.synth import synth_clips
+
+    waves, _ = synth_clips(300, seed=21)
+    rng = np.random.default_rng(4)
+    lens = rng.integers(1, 16001, size=300).astype(np.int32)
+    lens[:7] = [16000, 15997, 15998, 15999, 3, 4, 5]
+    pcm = np.clip(np.round(waves * 32768.0), -32768, 32767).astype(np.int16)
+    for i, n in enumerate(lens):
+        pcm[i, n:] = rng.integers(-30000, 30000, size=16000 - n)
+    ex = MfccExtractor(16000, 16000, 300)
+    nv = torch.as_tensor(lens).cuda()
+    a = ex(torch.as_tensor(pcm).cuda(), n_valid=nv)
+    ex.set(2, 1)
+    b = ex(torch.as_tensor(pcm).cuda(), n_valid=nv)
+    d = (a - b).abs().amax(dim=1).cpu().numpy()
+    assert d.max() < 1e-3, (int(d.argmax()), int(lens[d.argmax()]), float(d.max()))
+    # and a sample of rows against the oracle
+    for i in (0, 1, 2, 3, 4, 5, 6, 50, 131, 299):
+        ref = M.compute_mfcc_batch(pcm[i:i + 1, :lens[i]].astype(np.float32) / 32768.0)
+        assert np.abs(a[i:i + 1].cpu().numpy() - ref).max() < ATOL, (i, int(lens[i]))
+    ex.close()
+
+
+def test_ragged_and_int16_unsupported_plans_say_so(cuda):
     from lipasr.extract_features_construct_dataset import MfccExtractor
 
-    ex = MfccExtractor(44100, 4410, 4)  # a down-sampling rate: three-kernel path only
+    ex = MfccExtractor(44100, 4410, 4)  # a down-sampling rate: no fp16-plane resampler, no fused kernel
     assert not ex.fused
     w = torch.zeros(2, 4410, device="cuda")
     ex(w)
