@@ -27,7 +27,7 @@ from .parallel import DataParallel
 class TrainPipeline:
     def __init__(self, model, batch, sr_in=16000, n_samp=16000, utterance_length=44, rho=0.1, constraint="product",
                  affine=None, pgd=None, dp=None, use_graph=True, per_layer_iters=4, extractor=None, mfcc_cus="auto",
-                 sync_inputs=True, overlap_buckets=False, sync_bn=False):
+                 sync_inputs=True, overlap_buckets=False, sync_bn=False, train_cus="auto"):
         """constraint: 'product' (simple_norm_constraint, all layers), 'per_layer' (norm_constraint) or None.
         affine: (mean, scale) float64 device tensors [20*utterance_length] or None.
         pgd: dict(eps=, eps_step=, max_iter=) for adversarial training on the standardised features.
@@ -35,11 +35,15 @@ class TrainPipeline:
         ``speaker_recognition.WindowMfcc`` (441/220 windows -> 2020 features; pass utterance_length=101).
         mfcc_cus: how many of the GPU's CUs the feature-extraction stream may use (a CU-masked HIP stream, spread
         evenly over the XCDs); "auto" = the measured best share, None / 0 = no mask.
+        train_cus: "rest" confines the classifier's stream to the CUs the extraction stream does NOT use (a second CU-masked
+        stream: the chain's short kernels then never share a CU's LDS, wave slots and L1 with an MFCC workgroup), "all"
+        leaves it on every CU, "auto" = "rest" with the built-in MFCC plan.
         sync_inputs: order the extraction stream after the caller's current stream and the caller's stream after the
         extraction (two event hand-offs per step, ~50 us of a 0.4 ms step).  Needed whenever the tensors handed to step()
         were just produced on the caller's stream or are temporaries; a loop over a resident pool that was filled and
         synchronised beforehand (bench.py) may pass False."""
         self.sync_inputs = bool(sync_inputs)
+        self._train_cus = train_cus
         # Data parallel, gradient exchange.  False: two HIP graphs around ONE all-reduce of the whole flat buffer.  True:
         # three graphs around two buckets, everything but [dW_0 | db_0] (44 % of the bytes) reduced beside the dW_0 GEMM.
         # Measured on one MI355X with a one-rank RCCL group (identity collectives, scratch/nccl_one_rank.py): the extra
@@ -108,9 +112,16 @@ class TrainPipeline:
                 mfcc_cus = (n_cu * 7) // 8
             else:
                 # round 3 (resampler on the fp16 matrix instruction, dual-FFT STFT kernel: the MFCC needs 155 us of the
-                # whole chip instead of 240), 200-step runs: batch 1024: 0.499 / 0.460 / 0.481 / 0.493 / 0.499 ms with
-                # 96 / 128 / 160 / 192 / 224 CUs; batch 512: 0.341 with 128, 0.353 with 160 -> half the chip
-                mfcc_cus = n_cu // 2
+                # whole chip instead of 240), 200-step runs, classifier stream on every CU: batch 1024: 0.499 / 0.460 / 0.481 /
+                # 0.493 / 0.499 ms with 96 / 128 / 160 / 192 / 224 CUs; batch 512: 0.341 with 128, 0.353 with 160.
+                # With the classifier's stream on the REST of the chip (train_cus="rest", 300-step runs, three repeats within
+                # 0.002): batch 1024: 0.616 / 0.447 / 0.471 ms with 64 / 96 / 128 CUs for the MFCC (0.468 for the best shared
+                # schedule, 0.517 with 96 CUs and the classifier everywhere); batch 512: 0.339 / 0.346 with 64 / 96 (0.347 shared)
+                rest = self._train_cus == "rest" or (self._train_cus == "auto" and os.environ.get("LIPASR_TRAIN_CUS", "rest") == "rest")
+                if rest:
+                    mfcc_cus = (n_cu * 3) // 8 if self.batch > 768 else n_cu // 4
+                else:
+                    mfcc_cus = n_cu // 2
         if not mfcc_cus or mfcc_cus >= n_cu:
             return torch.cuda.Stream(device=self.dev)
         # Measured on MI355X (scratch/cu_mask_probe.py): mask bits act in groups of 8 consecutive bits -- group g
@@ -138,6 +149,18 @@ class TrainPipeline:
         # the three-kernel path's persistent resampler sizes its grid to one workgroup per CU it may use
         if hasattr(self.ex, "set"):
             self.ex.set(1, self.mfcc_cus)
+        # the classifier's stream on the CUs the MFCC stream does not use
+        want = self._train_cus if self._train_cus != "auto" else os.environ.get("LIPASR_TRAIN_CUS", "all" if self._custom_ex else "rest")
+        if want == "rest" and k < n_groups:
+            mask2 = (C.c_uint32 * words)()
+            for g in range(k, n_groups):
+                for b in range(8 * g, 8 * g + 8):
+                    mask2[b // 32] |= 1 << (b % 32)
+            st2 = N.c_s()
+            if N.lib.lipasr_stream_create_masked(self.h.h, mask2, words, C.byref(st2)) == N.OK:
+                self._masked_train_stream = st2
+                self.stream = torch.cuda.ExternalStream(st2.value, device=self.dev)
+                self.train_cus = 8 * (n_groups - k)
         return torch.cuda.ExternalStream(st.value, device=self.dev)
 
     # ---- pieces (all enqueue on the current stream)
@@ -328,7 +351,7 @@ class TrainPipeline:
         self._closed = True
         if not self.h.alive:  # the handle went first and took graphs and streams with it
             self._graphs.clear()
-            self._masked_stream = None
+            self._masked_stream = self._masked_train_stream = None
             return
         self.synchronize()
         for g in self._graphs.values():
@@ -339,6 +362,11 @@ class TrainPipeline:
         if st is not None:
             self._masked_stream = None
             self.mfcc_stream = torch.cuda.Stream(device=self.dev)
+            N.lib.lipasr_stream_destroy(self.h.h, st)
+        st = getattr(self, "_masked_train_stream", None)
+        if st is not None:
+            self._masked_train_stream = None
+            self.stream = torch.cuda.Stream(device=self.dev)
             N.lib.lipasr_stream_destroy(self.h.h, st)
         if not self._custom_ex:
             self.ex.close()  # the pipeline's own MFCC plan

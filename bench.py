@@ -228,6 +228,7 @@ def run_config(opt, pool, batch, rank, world, device, steps, warmup, profile):
     extras["train_graph_ms"] = pipe.train_ms()
     extras["mfcc_standalone_ms"] = standalone
     extras["mfcc_cus"] = getattr(pipe, "mfcc_cus", None)
+    extras["train_cus"] = getattr(pipe, "train_cus", None)
     extras["mfcc_stream"] = pipe.mfcc_stream_kind
     extras["n_cus"] = torch.cuda.get_device_properties(device).multi_processor_count
     extras["pool_clips"] = int(n_batches * batch)
@@ -394,6 +395,8 @@ def main():
                       "baseline_config": 5 if args.pgd else (2 if args.pre_extracted else (4 if world > 1 else 3)), "global_batch": global_batch, "per_gpu_batch": batch,
                       "clip": "1 s @ 16 kHz fp32", "resident_pool_clips_per_gpu": ex["pool_clips"], "parallelism": f"dp{world}", "hip_graph": not args.no_graph},
            "roofline": roofline, "mfcc_stream": ex.get("mfcc_stream"),
+           # CUs of the two CU-masked streams (disjoint): feature extraction | classifier chain
+           "cu_partition": {"mfcc": ex.get("mfcc_cus"), "classifier": ex.get("train_cus") or ex.get("n_cus")},
            # the classifier's part of the step (attack + fwd/bwd [+ all-reduce] + Adam + projection), HIP events on the training
            # stream while the next batch's MFCC runs on its own stream; TFLOP/s = 9.59 MFLOP/utt x batch / that time
            "train_graph_ms": round(ex["train_graph_ms"], 4), "classifier_tflops": round(cls_tflops, 2) if cls_tflops else None,
