@@ -438,8 +438,8 @@ constexpr size_t lds_gemm_bytes(int bk) {
   return ((size_t)(2 * 2 * bk * kLdsLD > 2 * 64 * 64 ? 2 * 2 * bk * kLdsLD : 2 * 64 * 64) + 8 * 16 * 8) * sizeof(float);
 }
 
-template <int AMODE, int BMODE, bool BF = false, int BK = kLdsBKMax>  // BK: k rows per LDS tile (32 or 64)
-__global__ __launch_bounds__(512) void gemm_lds_kernel(GemmArgs g) {
+template <int AMODE, int BMODE, bool BF, int BK>  // BK: k rows per LDS tile (32 or 64)
+__device__ __forceinline__ void gemm_lds_tile(const GemmArgs& g, const int bx, const int by, const int n_row_tiles) {
   constexpr int TS = 64;
   constexpr int NF = BK / kLdsBK;  // 32-row fetches per operand and tile
   extern __shared__ __attribute__((aligned(16))) float lds[];  // [buf][A|B][BK][68]; reused as [2][64][64]; then stat
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(512) void gemm_lds_kernel(GemmArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int kh = wave >> 2, wi = (wave >> 1) & 1, wj = wave & 1;
-  const int m0 = blockIdx.y * TS, n0 = blockIdx.x * TS;
+  const int m0 = by * TS, n0 = bx * TS;
   const int m_real = g.ones_row ? g.M - 1 : g.M;
   const int nst = (g.K + BK - 1) / BK;
   const bool ones = g.ones_row != 0;
@@ -574,30 +574,70 @@ __global__ __launch_bounds__(512) void gemm_lds_kernel(GemmArgs g) {
       float t = 0.0f;
 #pragma unroll
       for (int w = 0; w < 8; ++w) t += stat[(w * 16 + l4) * 8 + which * 4 + e];
-      if (n0 + col < g.N) g.part[((size_t)which * gridDim.y + blockIdx.y) * g.N + n0 + col] = t;
+      if (n0 + col < g.N) g.part[((size_t)which * n_row_tiles + by) * g.N + n0 + col] = t;
     }
   }
 }
 
+template <int AMODE, int BMODE, bool BF = false, int BK = kLdsBKMax>
+__global__ __launch_bounds__(512) void gemm_lds_kernel(GemmArgs g) {
+  gemm_lds_tile<AMODE, BMODE, BF, BK>(g, blockIdx.x, blockIdx.y, gridDim.y);
+}
+
+// The grouped launch with 64x64 LDS tiles: the weight-gradient GEMMs read both operands k-major (lin[k][i], dz[k][j]), which
+// is exactly the LDS image, so a tile is staged by plain float4 copies and every operand element leaves L2 once per 64x64
+// tile -- half the L2 -> CU traffic of the 32x32 fragment kernel (410 MB per step at batch 1024), which is what bounded it.
+template <int AMODE, int BMODE, bool BF = false>
+__global__ __launch_bounds__(512) void gemm_lds_grouped_kernel(GemmGroup grp) {
+  int p = 0;
+  while (p + 1 < grp.n && (int)blockIdx.x >= grp.tile_start[p + 1]) ++p;
+  const GemmArgs& g = grp.g[p];
+  const int local = blockIdx.x - grp.tile_start[p];
+  const int ntx = (g.N + 63) / 64;
+  gemm_lds_tile<AMODE, BMODE, BF, kLdsBKMax>(g, local % ntx, local / ntx, (g.M + 63) / 64);
+}
+
 // launches up to kMaxGroup weight-gradient style GEMMs (AMODE 1, BMODE 1) as one grid
+static int g_group_lds = 1;  // lipasr_debug_gemm_mode bit 3 clears it: the grouped launch on 32x32 fragment tiles (round 2)
+
 static int launch_gemm_group_tn(const GemmArgs* gs, int n, hipStream_t st) {
   int done = 0;
   while (done < n) {
     GemmGroup grp;
     memset(&grp, 0, sizeof(grp));
+    // 64x64 LDS tiles when the group is large enough to fill the chip with them (measured: bench config 3, batch 1024)
+    long big = 0;
+    for (int k = 0; k < kMaxGroup && done + k < n; ++k)
+      big += (long)((gs[done + k].N + 63) / 64) * ((gs[done + k].M + 63) / 64);
+    const bool lds_tiles = g_group_lds && big >= 128 && gs[done].K >= 64;
+    const int ts = lds_tiles ? 64 : 32;
     int k = 0, tiles = 0;
     for (; k < kMaxGroup && done + k < n; ++k) {
       const GemmArgs& g = gs[done + k];
       if (g.M <= 0 || g.N <= 0 || g.K <= 0) { set_error("grouped gemm: empty problem"); return LIPASR_EINVAL; }
       grp.g[k] = g;
       grp.tile_start[k] = tiles;
-      tiles += ((g.N + 31) / 32) * ((g.M + 31) / 32);
+      tiles += ((g.N + ts - 1) / ts) * ((g.M + ts - 1) / ts);
     }
     grp.n = k;
     grp.tile_start[k] = tiles;
-    const size_t lds = (size_t)(4 * 32 * 32 + 4 * 8 * 8) * sizeof(float);
-    if (gs[done].bf16) hipLaunchKernelGGL((gemm_f32_grouped_kernel<1, 1, 4, true>), dim3(tiles), dim3(256), lds, st, grp);
-    else hipLaunchKernelGGL((gemm_f32_grouped_kernel<1, 1, 4, false>), dim3(tiles), dim3(256), lds, st, grp);
+    if (lds_tiles) {
+      constexpr size_t lds_b = lds_gemm_bytes(kLdsBKMax);
+      static bool attr_set = false;
+      if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_lds_grouped_kernel<1, 1, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_lds_grouped_kernel<1, 1, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
+        attr_set = true;
+      }
+      if (gs[done].bf16) hipLaunchKernelGGL((gemm_lds_grouped_kernel<1, 1, true>), dim3(tiles), dim3(512), lds_b, st, grp);
+      else hipLaunchKernelGGL((gemm_lds_grouped_kernel<1, 1, false>), dim3(tiles), dim3(512), lds_b, st, grp);
+    } else {
+      const size_t lds = (size_t)(4 * 32 * 32 + 4 * 8 * 8) * sizeof(float);
+      if (gs[done].bf16) hipLaunchKernelGGL((gemm_f32_grouped_kernel<1, 1, 4, true>), dim3(tiles), dim3(256), lds, st, grp);
+      else hipLaunchKernelGGL((gemm_f32_grouped_kernel<1, 1, 4, false>), dim3(tiles), dim3(256), lds, st, grp);
+    }
     LP_LAUNCH_CHECK();
     done += k;
   }
@@ -992,6 +1032,7 @@ extern "C" {
 int lipasr_debug_gemm_mode(int mode) {
   g_gemm_mode = mode & 3;
   g_split_dw0 = (mode >> 2) & 1;
+  g_group_lds = ((mode >> 3) & 1) ? 0 : 1;
   return LIPASR_OK;
 }
 

@@ -395,7 +395,8 @@ int lipasr_debug_set(lipasr_handle_t h, int key, int value);
 
 /* Profiling knob: GEMM kernel choice. bits 0-1: 0 = automatic, 1 = split-K register kernel only, 2 = LDS-tiled kernel
  * wherever it is legal.  bit 2 (4): lipasr_mlp_train_fwd_bwd launches the first layer's weight gradient on its own
- * (as the data-parallel head / dw0 pair does) instead of inside the grouped launch. */
+ * (as the data-parallel head / dw0 pair does) instead of inside the grouped launch.  bit 3 (8): the grouped weight-gradient
+ * launch on 32x32 register-fragment tiles (round 2) instead of 64x64 LDS tiles. */
 int lipasr_debug_gemm_mode(int mode);
 
 /* Host-only (no GPU needed): copies one constant table, exactly as the kernels read it, into `out`
