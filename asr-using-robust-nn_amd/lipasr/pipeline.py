@@ -119,7 +119,9 @@ class TrainPipeline:
                 # schedule, 0.517 with 96 CUs and the classifier everywhere); batch 512: 0.339 / 0.346 with 64 / 96 (0.347 shared)
                 rest = self._train_cus == "rest" or (self._train_cus == "auto" and os.environ.get("LIPASR_TRAIN_CUS", "rest") == "rest")
                 if rest:
-                    mfcc_cus = (n_cu * 3) // 8 if self.batch > 768 else n_cu // 4
+                    # after the grouped dW GEMM moved to LDS tiles: batch 1024: 0.614 / 0.431 / 0.453 with 64 / 96 / 128;
+                    # batch 2048: 0.871 / 0.679 with 96 / 128; batch 512: 0.337 with 64
+                    mfcc_cus = n_cu // 4 if self.batch <= 768 else ((n_cu * 3) // 8 if self.batch <= 1536 else n_cu // 2)
                 else:
                     mfcc_cus = n_cu // 2
         if not mfcc_cus or mfcc_cus >= n_cu:
