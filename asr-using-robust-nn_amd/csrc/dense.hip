@@ -652,7 +652,8 @@ static bool use_lds_gemm(int M, int N, int K) {
   const bool legal = M >= 64 && N >= 64 && K >= 32;
   if (g_gemm_mode == 2) return legal;
   const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
-  return legal && tiles >= 224;  // measured on MI355X (scratch/time_gemm.py): it wins only when >= ~one tile per CU
+  static const long min_tiles = getenv("LIPASR_LDS_MIN_TILES") ? atol(getenv("LIPASR_LDS_MIN_TILES")) : 224;  // (A/B knob)
+  return legal && tiles >= min_tiles;  // measured on MI355X (scratch/time_gemm.py): it wins only when >= ~one tile per CU
 }
 
 template <int AMODE, int BMODE, int NW, bool BF>

@@ -117,7 +117,11 @@ class TrainPipeline:
                 # With the classifier's stream on the REST of the chip (train_cus="rest", 300-step runs, three repeats within
                 # 0.002): batch 1024: 0.616 / 0.447 / 0.471 ms with 64 / 96 / 128 CUs for the MFCC (0.468 for the best shared
                 # schedule, 0.517 with 96 CUs and the classifier everywhere); batch 512: 0.339 / 0.346 with 64 / 96 (0.347 shared)
-                rest = self._train_cus == "rest" or (self._train_cus == "auto" and os.environ.get("LIPASR_TRAIN_CUS", "rest") == "rest")
+                # PGD adversarial training is the other regime: the classifier's leg is ten times the MFCC's and throughput-bound
+                # on its GEMMs, so it keeps every CU (PGD-20, batch 1024: 4.09 ms with 128 CUs for the MFCC and the classifier
+                # everywhere; 4.14 / 4.25 with 64 / 32; on the rest of the chip only: 4.67 / 5.05 / 5.24 with 32 / 64 / 96)
+                rest = self._train_cus == "rest" or (self._train_cus == "auto" and not self.pgd
+                                                     and os.environ.get("LIPASR_TRAIN_CUS", "rest") == "rest")
                 if rest:
                     # after the grouped dW GEMM moved to LDS tiles: batch 1024: 0.614 / 0.431 / 0.453 with 64 / 96 / 128;
                     # batch 2048: 0.871 / 0.679 with 96 / 128; batch 512: 0.337 with 64
@@ -130,7 +134,8 @@ class TrainPipeline:
         # (bits 8g .. 8g+7) stands for CU g of every XCD, and the group is enabled when any of its bits is set.  So the
         # share is granted in steps of 8 CUs (one per XCD).
         # (pairs of settings 32 apart behaved alike -- 240/224, 208/192, 176/160, 144/128 -- so the share is rounded
-        # down to a multiple of 32 CUs, which is what the hardware appears to grant)
+        # down to a multiple of 32 CUs, which is what the hardware appears to grant; re-checked in round 3 with the two
+        # disjoint partitions: 13, 14 and 15 groups leave the STFT kernel's time where 12 groups put it, 0.267 ms)
         n_groups = max(1, n_cu // 8)
         k = max(4, min((int(mfcc_cus) // 32) * 4, n_groups))
         words = (n_cu + 31) // 32
@@ -152,7 +157,7 @@ class TrainPipeline:
         if hasattr(self.ex, "set"):
             self.ex.set(1, self.mfcc_cus)
         # the classifier's stream on the CUs the MFCC stream does not use
-        want = self._train_cus if self._train_cus != "auto" else os.environ.get("LIPASR_TRAIN_CUS", "all" if self._custom_ex else "rest")
+        want = self._train_cus if self._train_cus != "auto" else os.environ.get("LIPASR_TRAIN_CUS", "all" if (self._custom_ex or self.pgd) else "rest")
         if want == "rest" and k < n_groups:
             mask2 = (C.c_uint32 * words)()
             for g in range(k, n_groups):
