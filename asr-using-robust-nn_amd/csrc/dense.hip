@@ -85,6 +85,7 @@ struct GemmArgs {
   // 0: exact fp32 (v_mfma_f32_32x32x2_f32).  1: operands rounded to bf16 (RNE) at the MFMA, fp32 accumulate
   // (v_mfma_f32_32x32x16_bf16): BASELINE config 2's arithmetic; memory stays fp32.
   int bf16;
+  int lds_min_tiles;  // host side only: 64x64 tiles from which launch_gemm takes the LDS-tiled kernel (0 = the default)
 };
 
 // eight consecutive-k fp32 operand values of a lane -> one bf16 fragment (lane (r, h) holds k = 8 h + j, j < 8)
@@ -647,13 +648,14 @@ static int launch_gemm_group_tn(const GemmArgs* gs, int n, hipStream_t st) {
 static int g_gemm_mode = 0;  // 0 auto, 1 split-K kernel only, 2 LDS kernel wherever it is legal (profiling knob)
 static int g_split_dw0 = 0;  // lipasr_debug_gemm_mode bit 2: the first layer's weight gradient as its own launch
 
-static bool use_lds_gemm(int M, int N, int K) {
+constexpr int kLdsMinTiles = 224;  // measured on MI355X (scratch/time_gemm.py): the LDS kernel wins from ~one tile per CU
+
+static bool use_lds_gemm(int M, int N, int K, int min_tiles = 0) {
   if (g_gemm_mode == 1) return false;
   const bool legal = M >= 64 && N >= 64 && K >= 32;
   if (g_gemm_mode == 2) return legal;
   const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
-  static const long min_tiles = getenv("LIPASR_LDS_MIN_TILES") ? atol(getenv("LIPASR_LDS_MIN_TILES")) : 224;  // (A/B knob)
-  return legal && tiles >= min_tiles;  // measured on MI355X (scratch/time_gemm.py): it wins only when >= ~one tile per CU
+  return legal && tiles >= (min_tiles > 0 ? min_tiles : kLdsMinTiles);
 }
 
 template <int AMODE, int BMODE, int NW, bool BF>
@@ -689,7 +691,7 @@ static int launch_gemm(int amode, int bmode, const GemmArgs& g, hipStream_t st) 
     LP_LAUNCH_CHECK();
     return LIPASR_OK;
   }
-  if (use_lds_gemm(g.M, g.N, g.K)) {
+  if (use_lds_gemm(g.M, g.N, g.K, g.lds_min_tiles)) {
     const dim3 grid((g.N + 63) / 64, (g.M + 63) / 64);
     constexpr size_t lds_b = lds_gemm_bytes(kLdsBKMax);
 #define LP_LDS(A_, B_)                                                                              \
@@ -729,7 +731,7 @@ static int launch_gemm(int amode, int bmode, const GemmArgs& g, hipStream_t st) 
 }
 
 // row tiles of the *_STATS epilogues: must follow the kernel choice of launch_gemm for the same (M, N, K)
-static int stats_row_tiles(int M, int N, int K) { return use_lds_gemm(M, N, K) ? (M + 63) / 64 : (M + 31) / 32; }
+static int stats_row_tiles(int M, int N, int K, int min_tiles) { return use_lds_gemm(M, N, K, min_tiles) ? (M + 63) / 64 : (M + 31) / 32; }
 
 static GemmArgs gemm_args(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
                           int epi) {
@@ -1309,6 +1311,7 @@ static int train_fwd_bwd_impl(lipasr_mlp_t m, const float* params, float* bnstat
       g.correct_rows = correct_rows;
     }
     g.bf16 = m->compute_bf16;
+    g.lds_min_tiles = m->lds_min_tiles;
     if (LP_ON) {
       rc = launch_gemm(0, 1, g, st);
       if (rc != LIPASR_OK) return rc;
@@ -1320,7 +1323,7 @@ static int train_fwd_bwd_impl(lipasr_mlp_t m, const float* params, float* bnstat
       b.a = ws + L.offA; b.h = ws + L.offH; b.B = batch; b.N = L.n_out; b.has_bn = L.bn ? 1 : 0;
       b.Bstat = bstat;
       b.part = part;
-      b.n_tiles = stats_row_tiles(batch, L.n_out, L.n_in);
+      b.n_tiles = stats_row_tiles(batch, L.n_out, L.n_in, m->lds_min_tiles);
       if (L.bn) {
         b.gamma = params + L.offg; b.beta = params + L.offbe;
         b.mmean = bnstate + L.offmm; b.mvar = bnstate + L.offmv;
@@ -1358,6 +1361,7 @@ static int train_fwd_bwd_impl(lipasr_mlp_t m, const float* params, float* bnstat
     gx.part = part;
     if (P.bn) gx.save_mean = ws + P.offMean;
     gx.bf16 = m->compute_bf16;
+    gx.lds_min_tiles = m->lds_min_tiles;
     if (LP_ON) {
       rc = launch_gemm(0, 0, gx, st);
       if (rc != LIPASR_OK) return rc;
@@ -1369,7 +1373,7 @@ static int train_fwd_bwd_impl(lipasr_mlp_t m, const float* params, float* bnstat
       b.g = tmp; b.a = ws + P.offA; b.dz = ws + P.offDz; b.B = batch; b.N = P.n_out;
       b.Bstat = bstat; b.grad_scale = sa.grad_scale;
       b.part = part;
-      b.n_tiles = stats_row_tiles(batch, P.n_out, L.n_out);
+      b.n_tiles = stats_row_tiles(batch, P.n_out, L.n_out, m->lds_min_tiles);
       b.gamma = params + P.offg; b.save_mean = ws + P.offMean;
       b.dgamma = grads + P.offg; b.dbeta = grads + P.offbe;
       const dim3 grid((P.n_out + 127) / 128, (batch + kApplyRows - 1) / kApplyRows);
@@ -1441,12 +1445,12 @@ int lipasr_mlp_train_segment_exchange(lipasr_mlp_t m, int batch, int seg, size_t
   int cur = 0;
   for (int l = 0; l + 1 < m->n_layers; ++l)  // forward: layer l's GEMM closes a segment if layer l has BatchNorm
     if (m->L[l].bn) {
-      if (cur == seg) { *floats = 2 * (size_t)stats_row_tiles(batch, m->L[l].n_out, m->L[l].n_in) * m->L[l].n_out; return LIPASR_OK; }
+      if (cur == seg) { *floats = 2 * (size_t)stats_row_tiles(batch, m->L[l].n_out, m->L[l].n_in, m->lds_min_tiles) * m->L[l].n_out; return LIPASR_OK; }
       ++cur;
     }
   for (int l = m->n_layers - 1; l >= 1; --l)  // backward: the dX GEMM into layer l-1 closes one if layer l-1 has BatchNorm
     if (m->L[l - 1].bn) {
-      if (cur == seg) { *floats = 2 * (size_t)stats_row_tiles(batch, m->L[l - 1].n_out, m->L[l].n_out) * m->L[l - 1].n_out; return LIPASR_OK; }
+      if (cur == seg) { *floats = 2 * (size_t)stats_row_tiles(batch, m->L[l - 1].n_out, m->L[l].n_out, m->lds_min_tiles) * m->L[l - 1].n_out; return LIPASR_OK; }
       ++cur;
     }
   return LIPASR_OK;
@@ -1567,6 +1571,12 @@ int lipasr_mlp_output_vjp(lipasr_mlp_t m, const float* params, const float* bnst
                      probs_out, m->ws + m->offDzLast);
   LP_LAUNCH_CHECK();
   return backward_infer(m, params, bnstate, batch, dx, nullptr, nullptr, 0.0f, 0.0f, st);
+}
+
+int lipasr_mlp_set_gemm_tiles(lipasr_mlp_t m, int lds_min_tiles) {
+  LP_CHECK_ARG(m != nullptr && lds_min_tiles >= 0, "lipasr_mlp_set_gemm_tiles: bad argument");
+  m->lds_min_tiles = lds_min_tiles;
+  return LIPASR_OK;
 }
 
 int lipasr_mlp_set_compute(lipasr_mlp_t m, int mode) {

@@ -55,7 +55,7 @@ struct MfccPlan {
   float* d_mel_whi = nullptr;
   int* d_mel_pstart = nullptr;  // [128]
   int* d_mel_plen = nullptr;
-  float* d_dct = nullptr;  // [20][128]
+  float* d_dct = nullptr;  // DCT-II rows in MFMA fragment order: [32 rows (20 real)][k parity][64]
   float* d_y = nullptr;    // [batch_max][n_y]
   float* d_db = nullptr;   // [batch_max][n_frames][128]
   float* d_fmax = nullptr; // [batch_max][n_frames]
@@ -1548,28 +1548,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 // stage 3: top_db floor, DCT, layout
 // ---------------------------------------------------------------------------------------------
 
-constexpr int kDctFrames = 64;  // frames per workgroup (blockIdx.y = chunk): LDS stays 33 kB whatever the clip length
+constexpr int kDctFrames = 64;  // most frames per workgroup (blockIdx.y = chunk): LDS stays <= 33 kB whatever the clip length
 
-// One workgroup = one clip x 64 output frames, two wavefronts (32 frames each):
+// One workgroup = one clip x `chunk` <= 64 output frames, two wavefronts (32 frames each):
 //   out[c][t] = sum_m D[c][m] * max(dB[t][m], clipmax - 80)      c < 20 (padded to 32), m < 128
 // as a 32 x 32 x 128 contraction per wavefront on v_mfma_f32_32x32x2_f32 (the same ascending-m fp32 fma chain a
-// scalar loop would run): the DCT rows are the A operand (64 registers per lane, loaded from the L2-resident table
-// while the dB tile is on its way), the clamped dB tile is staged transposed in LDS (row stride 65: unit-stride,
-// conflict-free B-operand reads).  28 -> 10 us per 1024 clips against the one-output-per-thread LDS loop.
+// scalar loop would run): the DCT rows are the A operand (64 registers per lane: the table is stored in fragment order,
+// [row][k parity][64], so a lane's share is 16 float4 loads, requested together with the dB tile), the clamped dB tile is
+// staged transposed in LDS (row stride chunk + 1, odd: conflict-free writes, unit-stride B-operand reads).  The LDS
+// image follows the chunk (44 frames: 23 kB, six workgroups per CU instead of four).
 // n_frames = frames per clip the db / frame_max arrays are laid out for; with n_valid (clips of different lengths in
 // one launch) clip u has its own, smaller count and frames past it are zero columns, as fix_frames pads them
 // (extract_features_construct_dataset.py:33-37).
 __global__ __launch_bounds__(128) void dct_kernel(const float* __restrict__ db, const float* __restrict__ frame_max,
-                                                   int n_frames, int L, const float* __restrict__ dct,
+                                                   int n_frames, int L, int chunk, const float4* __restrict__ dct_frag,
                                                    const double* __restrict__ aff_mean,
                                                    const double* __restrict__ aff_scale, float* __restrict__ out,
                                                    const int* __restrict__ n_valid, int n_samp_max, int sr_in) {
-  __shared__ float dbs[128 * (kDctFrames + 1)];  // [m][t]
+  extern __shared__ float dbs[];  // [128][chunk + 1] = [m][t]
   __shared__ float red[2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, u = blockIdx.x;
   const int li = lane & 31, h = lane >> 5;
-  const int t0 = blockIdx.y * kDctFrames;             // first output frame of this chunk
-  const int tl = min(kDctFrames, L - t0);             // output frames of this chunk (incl. zero padding)
+  const int t0 = blockIdx.y * chunk;                  // first output frame of this chunk
+  const int tl = min(chunk, L - t0);                  // output frames of this chunk (incl. zero padding)
   int nf = n_frames;                                  // frames this clip really has
   if (n_valid) {
     int nvy, ny;
@@ -1577,17 +1578,22 @@ __global__ __launch_bounds__(128) void dct_kernel(const float* __restrict__ db, 
     nf = min(nf, n_frames);
   }
   const int tu = max(0, min(nf - t0, tl));            // of which computed from the spectrogram
-  constexpr int tp = kDctFrames + 1;
-  // dB tile: 64 frames x 128 mels = 64 floats per thread, ALL in flight at once (a plain loop keeps one load in
-  // flight per thread, and every load here is a cold-L2 round trip: that was 28 of the old kernel's 30 us)
+  const int tp = chunk + 1;
+  // dB tile: up to 64 frames x 128 mels = 64 floats per thread, ALL in flight at once (a plain loop keeps one load in
+  // flight per thread, and every load here is a cold-L2 round trip: that was 28 of the first kernel's 30 us)
   const float* src = db + ((size_t)u * n_frames + t0) * 128;
   const int n_live = tu * 128;
-  float stage[64];
+  float stage[kDctFrames];
 #pragma unroll
-  for (int j = 0; j < 64; ++j) {
+  for (int j = 0; j < kDctFrames; ++j) {
     const int i = tid + 128 * j;
     stage[j] = (i < n_live) ? src[i] : 0.0f;
   }
+  // A operand: lane (li, h) holds D[li][2 s + h], s < 64 (rows >= 20 are zero in the table)
+  float4 av4[16];
+  const float4* ap = dct_frag + (li * 2 + h) * 16;
+#pragma unroll
+  for (int s4 = 0; s4 < 16; ++s4) av4[s4] = ap[s4];
   float mx = -INFINITY;
   for (int t = tid; t < nf; t += 128) mx = fmaxf(mx, frame_max[(size_t)u * n_frames + t]);  // whole clip
   mx = wave_max(mx);
@@ -1595,21 +1601,23 @@ __global__ __launch_bounds__(128) void dct_kernel(const float* __restrict__ db, 
   __syncthreads();
   const float thr = fmaxf(red[0], red[1]) - 80.0f;  // top_db = 80
 #pragma unroll
-  for (int j = 0; j < 64; ++j) {
+  for (int j = 0; j < kDctFrames; ++j) {
     const int i = tid + 128 * j;  // frame j, mel tid: consecutive lanes, consecutive banks
-    dbs[tid * tp + j] = (i < n_live) ? fmaxf(stage[j], thr) : 0.0f;
+    if (j < chunk) dbs[tid * tp + j] = (i < n_live) ? fmaxf(stage[j], thr) : 0.0f;
   }
   __syncthreads();
-  // A operand (L2-resident 10 kB table): lane (li, h) holds D[li][2 s + h], s < 64 (rows >= 20 are zero)
-  float av[64];
-#pragma unroll
-  for (int s2 = 0; s2 < 64; ++s2) av[s2] = (li < kNMfcc) ? dct[li * 128 + 2 * s2 + h] : 0.0f;
   rs_f32x16 acc;
 #pragma unroll
   for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
-  const float* bp = dbs + h * tp + wave * 32 + li;
+  // (a wavefront whose 32 frames lie past the chunk still runs the chain on zeros of its own: columns >= chunk are never
+  // stored, and the reads stay inside the image: clamp the column)
+  const float* bp = dbs + h * tp + min(wave * 32 + li, chunk - 1);
 #pragma unroll
-  for (int s2 = 0; s2 < 64; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s2], bp[2 * s2 * tp], acc, 0, 0, 0);
+  for (int s4 = 0; s4 < 16; ++s4) {
+    const float a4[4] = {av4[s4].x, av4[s4].y, av4[s4].z, av4[s4].w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], bp[2 * (4 * s4 + e) * tp], acc, 0, 0, 0);
+  }
   // C layout: row (coefficient) = (q & 3) + 8 (q >> 2) + 4 h, column (frame) = li
   const int t = wave * 32 + li;
   const int n_out = kNMfcc * L;
@@ -1849,10 +1857,22 @@ static int launch_resample(const MfccPlan* p, const void* wav_any, int fmt, cons
   return LIPASR_OK;
 }
 
+// dct_kernel's A operand: lane (row li, k parity h) reads D[li][2 s + h], s < 64, as 16 float4
+static std::vector<float> dct_fragments() {
+  const std::vector<float> d = tables::dct_matrix();  // [20][128]
+  std::vector<float> f((size_t)32 * 2 * 64, 0.0f);
+  for (int li = 0; li < kNMfcc; ++li)
+    for (int h = 0; h < 2; ++h)
+      for (int s = 0; s < 64; ++s) f[((size_t)li * 2 + h) * 64 + s] = d[(size_t)li * 128 + 2 * s + h];
+  return f;
+}
+
 static int launch_dct(const MfccPlan* p, int batch, int L, const double* am, const double* as, float* out, const int* n_valid,
                       hipStream_t st) {
-  hipLaunchKernelGGL(dct_kernel, dim3(batch, (L + kDctFrames - 1) / kDctFrames), dim3(128), 0, st, p->d_db, p->d_fmax,
-                     p->n_frames, L, p->d_dct, am, as, out, n_valid, p->n_samp, p->sr_in);
+  const int chunk = std::min(kDctFrames, (L + 3) & ~3);  // even, so that the LDS row stride chunk + 1 is odd
+  const size_t lds = (size_t)128 * (chunk + 1) * sizeof(float);
+  hipLaunchKernelGGL(dct_kernel, dim3(batch, (L + chunk - 1) / chunk), dim3(128), lds, st, p->d_db, p->d_fmax, p->n_frames, L, chunk,
+                     reinterpret_cast<const float4*>(p->d_dct), am, as, out, n_valid, p->n_samp, p->sr_in);
   LP_LAUNCH_CHECK();
   return LIPASR_OK;
 }
@@ -2027,7 +2047,7 @@ static int plan_build(lipasr_handle_t h, int sr_in, int n_samp, int batch_max, i
   if ((rc = upload(&p->d_hann, hann_periodic())) != LIPASR_OK || (rc = upload(&p->d_tw, twiddles())) != LIPASR_OK ||
       (rc = upload(&p->d_mel_start, ms.start)) != LIPASR_OK || (rc = upload(&p->d_mel_len, ms.len)) != LIPASR_OK ||
       (rc = upload(&p->d_mel_off, ms.off)) != LIPASR_OK || (rc = upload(&p->d_mel_w, ms.w)) != LIPASR_OK ||
-      (rc = upload(&p->d_dct, dct_matrix())) != LIPASR_OK) {
+      (rc = upload(&p->d_dct, dct_fragments())) != LIPASR_OK) {
     mfcc_plan_free(p);
     return rc;
   }

@@ -35,5 +35,6 @@ struct lipasr_mlp {
   size_t ws_floats = 0;
   size_t offLogits = 0, offProb = 0, offDzLast = 0, offG0 = 0, offG1 = 0, offG2 = 0, offPart = 0;
   int compute_bf16 = 0;  // lipasr_mlp_set_compute: 1 rounds the GEMM operands to bf16 at the MFMA (fp32 accumulate)
+  int lds_min_tiles = 0;  // lipasr_mlp_set_gemm_tiles: training GEMMs take the LDS-tiled kernel from this many 64x64 tiles (0 = default)
 
 };

@@ -92,6 +92,7 @@ PROTOTYPES = {
     "lipasr_mlp_predict": (i32, [c_h, c_f, c_f, c_f, i32, c_f, c_f, c_s]),
     "lipasr_mlp_input_grad": (i32, [c_h, c_f, c_f, c_f, c_f, i32, c_f, c_s]),
     "lipasr_mlp_set_compute": (i32, [c_h, i32]),
+    "lipasr_mlp_set_gemm_tiles": (i32, [c_h, i32]),
     "lipasr_mlp_output_vjp": (i32, [c_h, c_f, c_f, c_f, c_f, i32, i32, c_f, c_f, c_s]),
     "lipasr_mlp_attack_step": (i32, [c_h, c_f, c_f, c_f, c_f, c_f, i32, f32, f32, c_s]),
     "lipasr_mlp_own_labels": (i32, [c_h, c_f, c_f, c_f, i32, c_f, c_s]),

@@ -168,6 +168,9 @@ class TrainPipeline:
                 self._masked_train_stream = st2
                 self.stream = torch.cuda.ExternalStream(st2.value, device=self.dev)
                 self.train_cus = 8 * (n_groups - k)
+                # on part of the chip the LDS-tiled GEMM pays from fewer tiles on (layer 2 forward, the dX GEMM into layer 2:
+                # 128 tiles): -16 us on the classifier's graph at 160 CUs (PGD, which keeps every CU, loses 8 % with it)
+                N.check(N.lib.lipasr_mlp_set_gemm_tiles(self.model._plan, 128))
         return torch.cuda.ExternalStream(st.value, device=self.dev)
 
     # ---- pieces (all enqueue on the current stream)

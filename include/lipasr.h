@@ -266,6 +266,13 @@ int lipasr_mlp_product_norm(lipasr_mlp_t m, const float* params, float* sigma_ou
  * next launch; re-capture HIP graphs after changing it. */
 int lipasr_mlp_set_compute(lipasr_mlp_t m, int mode);
 
+/* Kernel choice of the training pass's forward and dX GEMMs: from `lds_min_tiles` 64x64 output tiles on, the LDS-tiled
+ * kernel instead of the 32x32 register-fragment one (0 = the built-in 224, about one tile per CU of a whole MI355X).  A
+ * pipeline that confines the classifier to part of the chip lowers it (lipasr/pipeline.py: 128 on 160 CUs).  The two
+ * kernels split K differently, so results agree to fp32 rounding, not bit for bit.  Takes effect from the next launch;
+ * re-capture HIP graphs after changing it. */
+int lipasr_mlp_set_gemm_tiles(lipasr_mlp_t m, int lds_min_tiles);
+
 /* model.predict (train_constraints.py:109, attacks.py:344): inference mode (BN moving statistics,
  * no dropout).  probs and/or logits [batch][classes], either may be NULL. */
 int lipasr_mlp_predict(lipasr_mlp_t m, const float* params, const float* bnstate, const float* x,
