@@ -160,7 +160,7 @@ class TrainPipeline:
         want = self._train_cus if self._train_cus != "auto" else os.environ.get("LIPASR_TRAIN_CUS", "all" if (self._custom_ex or self.pgd) else "rest")
         if want == "rest" and k < n_groups:
             mask2 = (C.c_uint32 * words)()
-            for g in range(k, n_groups):
+            for g in range(k, n_groups):  # (partitions that share 32 or 64 CUs measured worse: 0.452-0.461 against 0.418 ms)
                 for b in range(8 * g, 8 * g + 8):
                     mask2[b // 32] |= 1 << (b % 32)
             st2 = N.c_s()
