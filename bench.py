@@ -135,6 +135,8 @@ def run_config(opt, pool, batch, rank, world, device, steps, warmup, profile):
     from lipasr.train_constraints import get_model
 
     waves, y = pool
+    if opt.get("int16"):  # 16-bit PCM pool: the same clips quantised as a wav file holds them
+        waves = (waves * 32768.0).round_().clamp_(-32768, 32767).to(torch.int16)
     n_batches = waves.shape[0] // batch
     # same seed on every rank: replicas start identical
     model = get_model(max_batch=batch, seed=0, compute_dtype="bfloat16" if opt.get("bf16") else "float32")
@@ -304,11 +306,12 @@ def main():
     ap.add_argument("--pre-extracted", action="store_true", help="BASELINE config 2: train from resident (N,880) features, no MFCC stage")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--skip-b512", action="store_true")
+    ap.add_argument("--int16", action="store_true", help="the resident pool as 16-bit PCM (what the corpus is): 2 bytes per sample in, scaled by 2^-15 on the device")
     ap.add_argument("--fit-api", action="store_true", help="only time the Keras-shaped fit() entry (used by the main run as a child process)")
     ap.add_argument("--skip-other-configs", action="store_true", help="do not add the config 2 / config 2 bf16 / config 5 records (N = 1 only)")
     args = ap.parse_args()
     opt = {"constraint": None if args.constraint == "none" else args.constraint, "pgd": args.pgd, "pgd_eps": args.pgd_eps, "bf16": args.bf16,
-           "pre_extracted": args.pre_extracted, "no_graph": args.no_graph}
+           "pre_extracted": args.pre_extracted, "no_graph": args.no_graph, "int16": args.int16}
 
     from lipasr.parallel import init_from_env
 
@@ -341,7 +344,8 @@ def main():
     ms = ex["mfcc_ms"]
     stage_ms = ms["resample"] + ms["stft_mel"] + ms["dct"]
     dom = max(("resample", "stft_mel", "dct"), key=lambda k: ms[k])
-    achieved = MFCC_BYTES_PER_UTT * batch / (stage_ms * 1e-3) / 1e9 if stage_ms > 0 else 0.0
+    bytes_per_utt = (32000 + 3520) if args.int16 else MFCC_BYTES_PER_UTT  # the 16-bit PCM variant reads 2 B per sample
+    achieved = bytes_per_utt * batch / (stage_ms * 1e-3) / 1e9 if stage_ms > 0 else 0.0
     # HBM traffic of the stage per launch: PMC counters cannot be read from inside this process, so the value is
     # the committed rocprofv3 measurement of the same kernels (separate --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH
     # doubled per MI355X_MICROARCH.md), scaled to this batch.
@@ -358,14 +362,16 @@ def main():
             break
         except Exception:
             continue
+    if args.int16:  # the committed counter passes ran on float32 clips
+        traffic, traffic_src, traffic_fused = None, None, None
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic, "traffic_source": traffic_src,
                 "stage": "MFCC (K1 = mfcc_fused_kernel [resample + STFT + mel + dB, timed in the stft_mel slot] + dct_kernel)" if ex.get("mfcc_fused") else "MFCC (K1 = resample + stft_mel + dct kernels)",
                 "dominant_kernel": ("mfcc_fused" if ex.get("mfcc_fused") and dom == "stft_mel" else dom) + "_kernel",
-                "algorithmic_bytes_per_utt": MFCC_BYTES_PER_UTT, "units_per_launch": batch,
+                "algorithmic_bytes_per_utt": bytes_per_utt, "units_per_launch": batch,
                 "kernel_ms": {k: round(ms[k], 4) for k in ("resample", "stft_mel", "dct")},
                 "fp32_flop_frac": round(MFCC_FLOP_PER_UTT * batch / (stage_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 5) if stage_ms > 0 else 0.0,
-                "traffic_x_algorithmic": round(traffic / (MFCC_BYTES_PER_UTT * batch), 3) if traffic else None,
+                "traffic_x_algorithmic": round(traffic / (bytes_per_utt * batch), 3) if traffic else None,
                 "fused_path_traffic": traffic_fused,  # the resample + STFT kernel (int16 / ragged input, or LIPASR_MFCC_FUSED=1): y stays in LDS
                 "note": "stage is fp32-compute-bound (8.7 MFLOP/utt vs 67.5 kB/utt): see DESIGN.md"}
     if ex.get("mfcc_cus"):
@@ -377,7 +383,7 @@ def main():
     if ex.get("mfcc_standalone_ms"):
         sa = ex["mfcc_standalone_ms"]
         sa_ms = sa["resample"] + sa["stft_mel"] + sa["dct"]
-        sa_ach = MFCC_BYTES_PER_UTT * batch / (sa_ms * 1e-3) / 1e9
+        sa_ach = bytes_per_utt * batch / (sa_ms * 1e-3) / 1e9
         roofline["standalone_whole_chip"] = {"kernel_ms": sa, "achieved": round(sa_ach, 2), "frac": round(sa_ach / HBM_PEAK_GBS, 5),
                                              "fp32_flop_frac": round(MFCC_FLOP_PER_UTT * batch / (sa_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 5)}
     cls_tflops = TRAIN_FLOP_PER_UTT * batch / (ex["train_graph_ms"] * 1e-3) / 1e12 if not args.pgd and ex["train_graph_ms"] > 0 else None
@@ -394,7 +400,7 @@ def main():
                                   + " -> Lipschitz-constrained MLP train step (Adam+NonNeg, simple_norm_constraint rho=0.1)" + (f" + PGD-{args.pgd} adversarial inner loop" if args.pgd else "")
                                   + (", data-parallel RCCL gradient all-reduce" if world > 1 else ", 1xMI355X"),
                       "baseline_config": 5 if args.pgd else (2 if args.pre_extracted else (4 if world > 1 else 3)), "global_batch": global_batch, "per_gpu_batch": batch,
-                      "clip": "1 s @ 16 kHz fp32", "resident_pool_clips_per_gpu": ex["pool_clips"], "parallelism": f"dp{world}", "hip_graph": not args.no_graph},
+                      "clip": "1 s @ 16 kHz int16 PCM" if args.int16 else "1 s @ 16 kHz fp32", "resident_pool_clips_per_gpu": ex["pool_clips"], "parallelism": f"dp{world}", "hip_graph": not args.no_graph},
            "roofline": roofline, "mfcc_stream": ex.get("mfcc_stream"),
            # CUs of the two CU-masked streams (disjoint): feature extraction | classifier chain
            "cu_partition": {"mfcc": ex.get("mfcc_cus"), "classifier": ex.get("train_cus") or ex.get("n_cus")},
@@ -416,6 +422,8 @@ def main():
         out["reference_config_2_pre_extracted_f32"] = _short(["--pre-extracted"], batch, k, w)
         out["reference_config_2_pre_extracted_bf16"] = _short(["--pre-extracted", "--bf16"], batch, k, w)
         out["reference_config_5_pgd20_1gpu"] = _short(["--pgd", "20", "--pgd-eps", "0.5"], batch, min(k, 20), min(w, 5))
+        # config 3 on 16-bit PCM clips (SURVEY 8d's 35 520 B/utt variant): the resampler reads int16 directly
+        out["reference_config_3_int16_pcm_input"] = _short(["--int16"], batch, k, w)
         try:  # the Keras-shaped fit() entry with the constraint as a callback, as train_constraints.py drives it
             import subprocess
 
