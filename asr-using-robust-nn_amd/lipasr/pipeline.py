@@ -68,7 +68,7 @@ class TrainPipeline:
         nf = 20 * self.L
         if model._widths[0] != nf:
             raise ValueError(f"model input width {model._widths[0]} != {nf}")
-        self._nbuf = 2  # feature/label buffers in flight (a third measured no different, CU-masked or not)
+        self._nbuf = 2  # feature/label buffers in flight (a third or fourth measured no different, CU-masked or not, balanced legs or not)
         self._feats2 = [torch.zeros(self.batch, nf, device=self.dev) for _ in range(self._nbuf)]
         self._labels2 = [torch.zeros(self.batch, model._n_classes, device=self.dev) for _ in range(self._nbuf)]
         self.feats, self.labels = self._feats2[0], self._labels2[0]  # buffers of the most recent step
