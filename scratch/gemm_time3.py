@@ -2,7 +2,7 @@ import sys, os; R=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); s
 import torch
 import lipasr._native as N
 h=N.get_handle(0)
-shapes=[('fwd0',0,0,1024,1024,880),('dX1',0,1,1024,1024,512),('dW0',1,0,880,1024,1024),('fwd1',0,0,1024,512,1024),('dW1',1,0,1024,512,1024)]
+shapes=[('fwd0',0,0,1024,1024,880),('x2',0,0,1024,2048,880),('x4',0,0,2048,2048,880),('x8',0,0,4096,2048,880),('dX1',0,1,1024,1024,512),('dW0',1,0,880,1024,1024),('fwd1',0,0,1024,512,1024),('dW1',1,0,1024,512,1024)]
 def run(ta,tb,M,Nn,K,mode):
     N.lib.lipasr_debug_gemm_mode(mode)
     A=torch.randn((K,M) if ta else (M,K),device='cuda'); Bm=torch.randn((Nn,K) if tb else (K,Nn),device='cuda'); Cc=torch.empty(M,Nn,device='cuda')
