@@ -159,48 +159,93 @@ def test_accuracy_parity_from_waveform(cuda, clips, seed):
     assert abs(acc_gpu - acc_ref) <= 0.005, (acc_gpu, acc_ref)
 
 
-def test_constrained_accuracy_gpu_features_vs_oracle_features(cuda, clips):
-    """The constrained model (train_constraints.py:63-105: NonNeg, simple_norm_constraint(0.1), the reference's dropout)
-    needs thousands of steps before BatchNorm's moving statistics (momentum 0.99) catch up with the projected weights;
-    a CPU oracle run of that length is minutes per seed, and shorter runs are chaotic -- the oracle against ITSELF with
-    1e-3 added to its features differs by 8 - 33 pt after 1 200 steps (scratch/sim_constrained_parity.py).  So the statement
-    is split: that the device arithmetic of a constrained step follows the oracle is test_pipeline_gpu /
-    test_mlp_gpu's; HERE the product trains the constrained model to convergence twice, once on its own MFCCs and once on
-    the ORACLE's MFCCs of the same waveforms, and the accuracy the reference reports -- the test accuracy of the
-    best-validation-loss checkpoint (ModelCheckpoint(save_best_only=True) then evaluate, train_constraints.py:104-111) --
-    must agree: what the MFCC stage's rounding does to the trained classifier.  A single constrained run scatters by about
-    +-1 pt (dropout masks and the best-checkpoint pick amplify any 1e-4 change of the features into a different trajectory:
-    rounds of this test gave 0.988 ... 0.997 for the same seed), so the +-0.5 pt statement is made on the mean over three
-    seeds (split, initialisation and data order change with the seed) and each pair is held to 1.5 pt."""
+def _train_constrained(spec, x, y, labels, seed, max_batch=512):
+    """train_constraints.py:91-111 with the protocol of tests/golden/make_constrained_acc.py: 400 epochs of 11 batches of
+    128 in order, simple_norm_constraint(0.1) after every step, validation loss every 10 epochs, test accuracy at the
+    best-validation-loss evaluation.  Returns (test accuracy at the best checkpoint, the model)."""
     from lipasr.Constraints import simple_norm_constraint
     from lipasr.keras import Dataset
 
-    waves, labels, ref_feats = clips
+    tr, va, te = _split(seed)
+    m = build_model(spec, max_batch=max_batch, seed=seed)
+    load_params(m, P.init_params(spec, seed=seed, dtype=np.float32, nonneg_init=True))
+    ds = Dataset.from_tensor_slices((x[tr], y[tr])).batch(128)
+    xv, yv, xt = dev(x[va]), dev(y[va]), dev(x[te])
+    cst = simple_norm_constraint(0.1, [])
+    best = (np.inf, None)
+    for _ in range(40):  # 40 x 10 epochs x 11 batches = 4 400 steps
+        m.fit(ds, epochs=10, verbose=0, callbacks=[cst])
+        vl, _ = m._evaluate_device(xv, yv, 512)
+        if vl < best[0]:
+            best = (vl, float(np.mean(m.predict_device(xt).argmax(1).cpu().numpy() == labels[te])))
+    return best[1], m
+
+
+def test_constrained_accuracy_product_vs_oracle(cuda, clips):
+    """BASELINE.json: "final top-1 accuracy within +-0.5 pt" for the model the north star names -- get_model() + NonNeg +
+    simple_norm_constraint(0.1) after every batch (VD/train_constraints.py:63-111) -- PRODUCT against ORACLE.
+
+    Oracle side: tests/golden/constrained_acc.npz, written on the CPU by tests/golden/make_constrained_acc.py: oracle.mlp_ref +
+    oracle.constraints_ref.simple_norm_constraint_pass trained to convergence (4 400 steps, float32, the reference's dropout) on
+    the ORACLE's MFCCs of the 2 366 synthetic clips, five seeds (split, initialisation), each with two independent dropout
+    streams A and B.  Product side, here: the same five seeds, same split / initial weights / batch order / schedule / model
+    selection, trained by the HIP kernels from the WAVEFORM (K1 features, A2 on the device, K2/K5/K3 steps, Philox dropout).
+    Nothing is shared but the waveforms, the initial weights and the protocol.
+
+    Dropout cannot be matched draw for draw, so single runs scatter: the oracle against ITSELF with another dropout
+    stream moves by up to `scatter` (read from the fixture, 1.2 pt when it was written; 0.3 pt typical).  Statement asserted:
+    |mean_product - mean_oracle| <= 0.5 pt over the five seeds, and every product run within the oracle's own same-seed
+    scatter (+ one test clip) of that seed's oracle runs."""
+    import os
+
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "constrained_acc.npz"))
+    seeds = [int(s) for s in fx["seeds"]]
+    oa, ob = fx["acc_stream_a"], fx["acc_stream_b"]
+    scatter = float(np.abs(oa - ob).max())
+    waves, labels, _ = clips
     y = P.to_categorical(labels, 10)
     spec = P.vd_constrained_spec()
     m0 = build_model(spec, max_batch=128, seed=0)
     raw, feats = _product_side(cuda, waves, m0)
     m0.close()
-    mean, scale = P.standard_scaler_fit(ref_feats)
-    sets = {"product MFCC": feats.cpu().numpy(), "oracle MFCC": ((ref_feats - mean) / scale).astype(np.float32)}
-    accs = {name: [] for name in sets}
-    for seed, (name, x) in [(sd, it) for sd in (3, 4, 5) for it in sets.items()]:
-        tr, va, te = _split(seed)
-        m = build_model(spec, max_batch=512, seed=seed)
-        load_params(m, P.init_params(spec, seed=seed, dtype=np.float32, nonneg_init=True))
-        ds = Dataset.from_tensor_slices((x[tr], y[tr])).batch(128)
-        xv, yv, xt = dev(x[va]), dev(y[va]), dev(x[te])
-        cst = simple_norm_constraint(0.1, [])
-        best = (np.inf, None)
-        for epoch in range(40):  # 40 x 10 epochs x 11 batches = 4 400 steps
-            m.fit(ds, epochs=10, verbose=0, callbacks=[cst])
-            vl, _ = m._evaluate_device(xv, yv, 512)
-            if vl < best[0]:
-                best = (vl, float(np.mean(m.predict_device(xt).argmax(1).cpu().numpy() == labels[te])))
-        accs[name].append(best[1])
+    x = feats.cpu().numpy()
+    acc = []
+    for seed in seeds:
+        a, m = _train_constrained(spec, x, y, labels, seed)
         m.close()
-    a, b = np.array(accs["product MFCC"]), np.array(accs["oracle MFCC"])
-    print(f"\nconstrained model, seeds 3-5: test accuracy at the best-validation checkpoint, product MFCC {a} mean {a.mean():.4f}, oracle MFCC {b} mean {b.mean():.4f}")
-    assert min(a.min(), b.min()) > 0.9
-    assert abs(a.mean() - b.mean()) <= 0.005   # +-0.5 pt on the mean
-    assert np.abs(a - b).max() <= 0.015        # a single pair: the run-to-run scatter of a constrained run
+        acc.append(a)
+    acc = np.array(acc)
+    o_mean = 0.5 * (oa.mean() + ob.mean())
+    print(f"\nconstrained model, seeds {seeds}: test accuracy at the best-validation checkpoint\n  product (from the waveform) {acc} mean {acc.mean():.4f}"
+          f"\n  oracle stream A {oa} mean {oa.mean():.4f}\n  oracle stream B {ob} mean {ob.mean():.4f}\n  oracle same-seed scatter max {scatter:.4f}")
+    assert acc.min() > 0.95
+    assert abs(acc.mean() - o_mean) <= 0.005  # +-0.5 pt, product mean against oracle mean
+    one_clip = 1.0 / 666
+    lo, hi = np.minimum(oa, ob) - scatter - one_clip, np.maximum(oa, ob) + scatter + one_clip
+    assert np.all((acc >= lo) & (acc <= hi)), (acc, lo, hi)
+
+
+def test_constrained_training_is_bitwise_reproducible(cuda, clips):
+    """DESIGN: no float atomics anywhere, Philox dropout keyed by (seed, element, layer, step) => the same seed on the same
+    features gives the SAME bits.  Two fresh models, 330 constrained steps each with the reference's dropout: every parameter,
+    BatchNorm statistic and Adam moment must be bit-identical, so run-to-run accuracy scatter of this model is chaos
+    (sensitivity to 1e-7 feature changes and to the dropout stream), never nondeterminism of the kernels."""
+    from lipasr.Constraints import simple_norm_constraint
+    from lipasr.keras import Dataset
+
+    waves, labels, ref_feats = clips
+    mean, scale = P.standard_scaler_fit(ref_feats)
+    x = ((ref_feats - mean) / scale).astype(np.float32)
+    y = P.to_categorical(labels, 10)
+    tr, _, _ = _split(3)
+    spec = P.vd_constrained_spec()
+    states = []
+    for _ in range(2):
+        m = build_model(spec, max_batch=512, seed=3)
+        load_params(m, P.init_params(spec, seed=3, dtype=np.float32, nonneg_init=True))
+        ds = Dataset.from_tensor_slices((x[tr], y[tr])).batch(128)
+        m.fit(ds, epochs=30, verbose=0, callbacks=[simple_norm_constraint(0.1, [])])
+        states.append(m._state_dict())
+        m.close()
+    for k in states[0]:
+        assert torch.equal(states[0][k], states[1][k]), k
