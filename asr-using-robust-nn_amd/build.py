@@ -14,8 +14,11 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lipasr", "liblipasr.so")
-SOURCES = ["core.hip", "spectral.hip", "dense.hip", "optim.hip", "mfcc.hip"]
-HEADERS = ["common.h", "mlp.h", "mfcc_tables.h", os.path.join("..", "..", "include", "lipasr.h")]
+SOURCES = ["core.hip", "spectral.hip", "dense.hip", "optim.hip", "mfcc.hip", "stft_bdft.hip"]
+HEADERS = ["common.h", "mlp.h", "mfcc_tables.h", "stft.h", os.path.join("..", "..", "include", "lipasr.h")]
+# per-source flags.  stft_bdft.hip: the SLP vectoriser turns the kernel's scalar fp32 chains into v_pk_* with a v_mov per operand
+# pair (111 moves per frame), which also cost 39 spilled registers; measured 166 us with it, 118 us without (round 4).
+EXTRA = {"stft_bdft.hip": ["-fno-slp-vectorize"]}
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-fgpu-rdc" if False else "-fno-gpu-rdc"]
 
@@ -43,7 +46,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     for s in SOURCES:
         obj = os.path.join(HERE, "build", s.replace(".hip", ".o"))
-        cmd = [_hipcc(), *FLAGS, "-c", os.path.join(CSRC, s), "-o", obj]
+        cmd = [_hipcc(), *FLAGS, *EXTRA.get(s, []), "-c", os.path.join(CSRC, s), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -16,6 +16,7 @@
 //                          major layout, optional fused StandardScaler affine.
 #include "common.h"
 #include "mfcc_tables.h"
+#include "stft.h"
 #include <type_traits>
 
 namespace lipasr {
@@ -65,6 +66,10 @@ struct MfccPlan {
   std::vector<hipEvent_t> prof_events;
   int prof_cap = 0, prof_n = 0;
   bool prof_half = false;  // slot prof_n already holds a resample timing
+  // block-DFT STFT on the matrix pipe (stft_bdft.hip): the default 2048/512 path; stage-mask bit 8 (256) selects the Stockham
+  // kernel stft_mel2_kernel instead (the parity reference)
+  BdftTables bd;
+  int bd_seg = 44;  // frames per workgroup (a multiple of 4; 44 = a whole 1-s clip)
 };
 
 void mfcc_plan_free(MfccPlan* p) {
@@ -74,16 +79,8 @@ void mfcc_plan_free(MfccPlan* p) {
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   for (hipEvent_t e : p->prof_events) (void)hipEventDestroy(e);
+  bdft_tables_free(&p->bd);
   delete p;
-}
-
-// per-clip lengths, the expressions of tables::resampled_lengths (librosa.load -> resampy int(n ratio), fix_length ceil)
-__device__ __forceinline__ void clip_lengths(int n, int sr_in, int* n_vy, int* n_y, int* n_frames) {
-  const double r = (double)kSr / (double)sr_in;
-  const double v = (double)n * r;
-  *n_vy = (int)v;
-  *n_y = (int)ceil(v);
-  *n_frames = (*n_y >= 2) ? 1 + *n_y / kHop : 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -545,21 +542,6 @@ __global__ __launch_bounds__(256) void copy_pad_kernel(const float* __restrict__
 constexpr int kFftLds = 2048 + 72;  // + room for the four weighted-power arrays laid over one buffer
 __device__ __forceinline__ int padi(int i) { return i ^ ((i >> 4) & 7); }
 
-// np.pad(y, 1024, mode='reflect') index: position j relative to y[0], any j, n >= 2
-__device__ __forceinline__ int reflect_index(int j, int n) {
-  if ((unsigned)j < (unsigned)n) return j;  // interior frames never reflect
-  const int period = 2 * (n - 1);
-  int m = j % period;
-  if (m < 0) m += period;
-  return m < n ? m : period - m;
-}
-
-// the same for a clip longer than the padding (n > 2048 >= any |overshoot|): one reflection, no division
-__device__ __forceinline__ int reflect_once(int j, int n) {
-  const int lo = j < 0 ? -j : j;
-  return lo < n ? lo : 2 * (n - 1) - lo;
-}
-
 struct cpx { float re, im; };
 __device__ __forceinline__ cpx cadd(cpx a, cpx b) { return {a.re + b.re, a.im + b.im}; }
 __device__ __forceinline__ cpx csub(cpx a, cpx b) { return {a.re - b.re, a.im - b.im}; }
@@ -641,24 +623,6 @@ __device__ __forceinline__ void fft_pass(float2* __restrict__ buf, int Ns, int j
   for (int r = 0; r < R; ++r) dst[padi(j0 + r * Ns)] = make_float2(v[r].re, v[r].im);
   }
 }
-
-struct StftArgs {
-  const float* y;  // [B][n_y]
-  int n_y, n_frames;
-  const float* hann;
-  const float2* tw;
-  const float* mel_wlo;  // [1025]
-  const float* mel_whi;  // [1025]
-  const int* mel_start;  // [128] run of bins whose lower filter is m
-  const int* mel_len;
-  float* db;    // [B][n_frames][128]
-  float* fmax;  // [B][n_frames]
-  int stage_mask;  // profiling only: bit0 skip the FFT passes, bit1 skip the mel reduction (results are wrong)
-  // clips of different lengths in one launch (stft_mel2_kernel): samples per clip, or null; n_y / n_frames above are then the
-  // longest clip's (the strides of y, db, fmax) and every clip uses its own
-  const int* n_valid;
-  int sr_in, n_samp_max;
-};
 
 constexpr int kTPair = 1028;    // stride of the two float2 (frame 0, frame 1) weighted-power arrays, >= 1025 bins
 
@@ -861,11 +825,6 @@ __device__ __forceinline__ cp2 tocp2(float4 t) { return {v2f{t.x, t.y}, v2f{t.z,
     dft8_2(v);                                                                             \
     _Pragma("unroll") for (int r = 0; r < 8; ++r) st4(wr + (WO(r)), v[r]);                 \
   }
-
-__device__ __forceinline__ void lds_barrier2() {
-  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): LDS traffic only (the kernel's global stores need no ordering)
-  __builtin_amdgcn_s_barrier();
-}
 
 // Four frames (f0 .. f0 + 3) of clip u: two complex FFTs in packed lock step, powers, mel, dB.  On return thread (pr = tid >> 7,
 // m = tid & 127) holds the dB values of mel bin m for frames f0 + 2 pr (dbe) and f0 + 2 pr + 1 (dbo), which it has also
@@ -1932,6 +1891,9 @@ static int launch_from_22k(const MfccPlan* p, const float* y, const int* n_valid
       LP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dft_mel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)dl));
     hipLaunchKernelGGL(dft_mel_kernel, dim3((d.total_rows + kDftRows - 1) / kDftRows), dim3(64 * p->dft_tiles), dl, st, d);
+  } else if (stft2_ok(p) && p->bd.cfrag && !(p->stage_mask & 256)) {
+    const int rc = launch_stft_bdft(a, p->bd, batch, p->bd_seg, st);
+    if (rc != LIPASR_OK) return rc;
   } else if (stft2_ok(p)) {
     hipLaunchKernelGGL(stft_mel2_kernel, dim3((p->n_frames + 3) / 4, batch), dim3(256), 0, st, a);
   } else {
@@ -2051,6 +2013,7 @@ static int plan_build(lipasr_handle_t h, int sr_in, int n_samp, int batch_max, i
     mfcc_plan_free(p);
     return rc;
   }
+  if (!dft && (rc = bdft_tables_build(&p->bd)) != LIPASR_OK) { mfcc_plan_free(p); return rc; }
   const size_t ny = (size_t)batch_max * p->n_y, ndb = (size_t)batch_max * p->n_frames * 128,
                nfm = (size_t)batch_max * p->n_frames;
   if (hipMalloc(&p->d_y, ny * sizeof(float)) != hipSuccess || hipMalloc(&p->d_db, ndb * sizeof(float)) != hipSuccess ||
@@ -2181,7 +2144,12 @@ static int plan_profile_end(MfccPlan* p, float* avg_ms3, int* n_calls) {
 
 static int plan_set(MfccPlan* p, int key, int value) {
   LP_CHECK_ARG(p != nullptr, "lipasr_mfcc_set: null plan");
-  LP_CHECK_ARG(key >= 0 && key <= 2, "lipasr_mfcc_set: unknown key %d", key);
+  LP_CHECK_ARG(key >= 0 && key <= 3, "lipasr_mfcc_set: unknown key %d", key);
+  if (key == 3) {
+    LP_CHECK_ARG(value >= 4 && value <= 4096 && (value & 3) == 0, "lipasr_mfcc_set: frames per workgroup %d (a multiple of 4)", value);
+    p->bd_seg = value;
+    return LIPASR_OK;
+  }
   if (key == 2) {
     p->prefer_fused = value != 0;
     return LIPASR_OK;
