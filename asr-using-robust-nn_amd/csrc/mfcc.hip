@@ -1892,8 +1892,16 @@ static int launch_from_22k(const MfccPlan* p, const float* y, const int* n_valid
                                  (int)dl));
     hipLaunchKernelGGL(dft_mel_kernel, dim3((d.total_rows + kDftRows - 1) / kDftRows), dim3(64 * p->dft_tiles), dl, st, d);
   } else if (stft2_ok(p) && p->bd.cfrag && !(p->stage_mask & 256)) {
-    const int rc = launch_stft_bdft(a, p->bd, batch, p->bd_seg, st);
+    // one workgroup per clip: the kernel finishes with the top_db floor and the DCT itself (stage-mask bit 9 keeps dct_kernel)
+    const bool fuse = !(p->stage_mask & 512) && bdft_can_fuse_dct(p->n_frames, p->bd_seg, L);
+    BdftDct d;
+    d.L = L; d.dct_frag = reinterpret_cast<const float4*>(p->d_dct); d.aff_mean = am; d.aff_scale = as; d.out = out;
+    const int rc = launch_stft_bdft(a, p->bd, batch, p->bd_seg, fuse ? &d : nullptr, st);
     if (rc != LIPASR_OK) return rc;
+    if (fuse) {
+      if (mid) LP_HIP(hipEventRecord(mid, st));
+      return LIPASR_OK;
+    }
   } else if (stft2_ok(p)) {
     hipLaunchKernelGGL(stft_mel2_kernel, dim3((p->n_frames + 3) / 4, batch), dim3(256), 0, st, a);
   } else {

@@ -64,6 +64,16 @@ struct BdftTables {
 };
 int bdft_tables_build(BdftTables* t);
 void bdft_tables_free(BdftTables* t);
-int launch_stft_bdft(const StftArgs& a, const BdftTables& t, int batch, int seg_frames, hipStream_t st);
+// `dct`: when non-null and one workgroup covers a whole clip (seg_frames >= n_frames <= 64, L <= 64), the kernel also applies the
+// top_db floor and the DCT (+ optional StandardScaler affine) and writes the features: no dct_kernel launch afterwards.
+struct BdftDct {
+  int L = 0;                        // utterance_length: output frames per clip
+  const float4* dct_frag = nullptr; // DCT-II rows in MFMA fragment order (MfccPlan::d_dct)
+  const double* aff_mean = nullptr;
+  const double* aff_scale = nullptr;
+  float* out = nullptr;             // [batch][20 * L]
+};
+bool bdft_can_fuse_dct(int n_frames, int seg_frames, int L);
+int launch_stft_bdft(const StftArgs& a, const BdftTables& t, int batch, int seg_frames, const BdftDct* dct, hipStream_t st);
 
 }  // namespace lipasr

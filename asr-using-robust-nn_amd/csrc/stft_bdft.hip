@@ -57,6 +57,12 @@ struct BdftArgs {
   const unsigned long long* smask;
   const int4* mpos;
   int seg_frames;
+  // fused top_db floor + DCT epilogue (one workgroup per clip); L = 0: off
+  int L;
+  const float4* dct_frag;
+  const double* aff_mean;
+  const double* aff_scale;
+  float* out;
 };
 
 // Eight fp32 values -> two fp16 planes as matrix operands: hi = RNE(x), lo = RNE(x - hi) (v_fma_mix: the subtraction reads hi as
@@ -141,7 +147,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     n_frames = min(n_frames, a.st.n_frames);
   }
   const int F0 = blockIdx.x * a.seg_frames;
-  if (F0 >= n_frames) return;  // (workgroup-uniform, before any barrier)
+  // (workgroup-uniform, before any barrier.  With the fused epilogue a clip without a frame still gets its zero columns,
+  // fix_frames' padding, extract_features_construct_dataset.py:33-37)
+  if (F0 >= n_frames && a.L <= 0) return;
   const int F1 = min(F0 + a.seg_frames, n_frames);
   // constant operands of the two matrix stages: 64 registers for the whole kernel
   bd_h8 ch[4], cl[4], eh[4], el[4];
@@ -159,7 +167,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   for (int i = 0; i < kBdTwF4 / 256; ++i) twl[tid + 256 * i] = a.tw[tid + 256 * i];
   __syncthreads();
   const float* yu = a.st.y + (size_t)u * a.st.n_y;
-  const int n_iter = (F1 - F0 + 3) >> 2;
+  const int n_iter = (F0 < n_frames) ? (F1 - F0 + 3) >> 2 : -1;  // -1: no frame, the loop below does not run
   const int k2 = li & 15, plane = li >> 4;
   // segment ends summed into mel `lane` and mel `lane + 64`: 12 staging positions, two per register
   unsigned mp[6];
@@ -168,10 +176,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     mp[0] = (unsigned)pa0.x | ((unsigned)pa0.y << 16); mp[1] = (unsigned)pa0.z | ((unsigned)pb0.x << 16); mp[2] = (unsigned)pb0.y | ((unsigned)pb0.z << 16);
     mp[3] = (unsigned)pa1.x | ((unsigned)pa1.y << 16); mp[4] = (unsigned)pa1.z | ((unsigned)pb1.x << 16); mp[5] = (unsigned)pb1.y | ((unsigned)pb1.z << 16);
   }
+  float clip_max = -INFINITY;  // over this wavefront's frames (fused epilogue)
   float ys[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) ys[i] = 0.0f;
-  if (wave >= 1) bd_fetch(yu, F0 + wave - 1, li, h, n_y, n_vy, ys);  // iteration -1: blocks 0 .. 2 by wavefronts 1 .. 3
+  if (wave >= 1 && n_iter >= 0) bd_fetch(yu, F0 + wave - 1, li, h, n_y, n_vy, ys);  // iteration -1: blocks 0 .. 2 by wavefronts 1 .. 3
   for (int it = -1; it < n_iter; ++it) {
     // ---------------------------------------------------------------- one block per wavefront
     const int rel = 4 * it + wave + 3;  // relative to F0; iteration -1 fills blocks 0 .. 2 (wavefronts 1 .. 3)
@@ -339,6 +348,70 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       dbp[lane + 64] = d1;
       const float mx = bd_wave_max(fmaxf(d0, d1));
       if (lane == 0) a.st.fmax[(size_t)u * a.st.n_frames + f] = mx;
+      clip_max = fmaxf(clip_max, mx);
+    }
+  }
+  if (a.L <= 0) return;
+  // ---------------------------------------------------------------- fused epilogue: dct_kernel's arithmetic, instruction for
+  // instruction (mfcc.hip), on this workgroup's own dB tile: top_db floor against the clip maximum, DCT-II as a 32 x 32 x 128
+  // contraction per wavefront on v_mfma_f32_32x32x2_f32 (wavefronts 0 and 1: 32 frames each), optional affine in fp64.  The
+  // tile comes back from L2 (this workgroup stored it); the ring is free now and holds the transposed image.
+  {
+    float* dbs = ring;                       // [128][tp] = [m][t]
+    float* red = ring + 128 * 65;            // 4 floats behind the largest image
+    const int L = a.L, nf = n_frames;
+    const int chunk = min(64, (L + 3) & ~3), tp = chunk + 1;
+    const int tl = min(chunk, L), tu = max(0, min(nf, tl));
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wavefront's dB stores have left
+    lds_barrier2();                      // every wavefront is done with its staging slot: the ring is free
+    if (lane == 0) red[wave] = clip_max;
+    __syncthreads();
+    const float thr = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) - 80.0f;  // top_db = 80
+    const float* src = a.st.db + (size_t)u * a.st.n_frames * 128;
+    const int n_live = tu * 128;
+    float stage[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      const int i = tid + 256 * j;  // frame 2 j + (tid >> 7), mel tid & 127
+      stage[j] = (i < n_live) ? __builtin_nontemporal_load(src + i) : 0.0f;
+    }
+    float4 av4[16];
+    const float4* ap = a.dct_frag + (li * 2 + h) * 16;
+    if (wave < 2) {
+#pragma unroll
+      for (int s4 = 0; s4 < 16; ++s4) av4[s4] = ap[s4];
+    }
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      const int i = tid + 256 * j, t = 2 * j + (tid >> 7);
+      if (t < chunk) dbs[(tid & 127) * tp + t] = (i < n_live) ? fmaxf(stage[j], thr) : 0.0f;
+    }
+    __syncthreads();
+    if (wave < 2) {
+      bd_f32x16 acc;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+      const float* bp = dbs + h * tp + min(wave * 32 + li, chunk - 1);
+#pragma unroll
+      for (int s4 = 0; s4 < 16; ++s4) {
+        const float a4[4] = {av4[s4].x, av4[s4].y, av4[s4].z, av4[s4].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], bp[2 * (4 * s4 + e) * tp], acc, 0, 0, 0);
+      }
+      const int t = wave * 32 + li;
+      const int n_out = kNMfcc * L;
+      if (t < tl) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int c = (q & 3) + 8 * (q >> 2) + 4 * h;
+          if (c < kNMfcc) {
+            float v = (t < tu) ? acc[q] : 0.0f;
+            const int oo = c * L + t;
+            if (a.aff_mean) v = (float)(((double)v - a.aff_mean[oo]) / a.aff_scale[oo]);
+            a.out[(size_t)u * n_out + oo] = v;
+          }
+        }
+      }
     }
   }
 }
@@ -465,9 +538,18 @@ int bdft_tables_build(BdftTables* t) {
   return LIPASR_OK;
 }
 
-int launch_stft_bdft(const StftArgs& st, const BdftTables& t, int batch, int seg_frames, hipStream_t stream) {
+bool bdft_can_fuse_dct(int n_frames, int seg_frames, int L) {
+  seg_frames = std::max(4, (seg_frames + 3) & ~3);
+  return seg_frames >= n_frames && n_frames <= 64 && L >= 1 && L <= 64;
+}
+
+int launch_stft_bdft(const StftArgs& st, const BdftTables& t, int batch, int seg_frames, const BdftDct* dct, hipStream_t stream) {
   BdftArgs a;
   a.st = st;
+  a.L = 0; a.dct_frag = nullptr; a.aff_mean = nullptr; a.aff_scale = nullptr; a.out = nullptr;
+  if (dct && bdft_can_fuse_dct(st.n_frames, seg_frames, dct->L)) {
+    a.L = dct->L; a.dct_frag = dct->dct_frag; a.aff_mean = dct->aff_mean; a.aff_scale = dct->aff_scale; a.out = dct->out;
+  }
   a.cfrag = t.cfrag; a.efrag = t.efrag; a.tw = t.tw; a.wlo = t.wlo; a.whi = t.whi; a.smask = t.smask; a.mpos = t.mpos;
   seg_frames = std::max(4, (seg_frames + 3) & ~3);
   a.seg_frames = seg_frames;
