@@ -798,6 +798,23 @@ __device__ __forceinline__ void sum_partials(const float* __restrict__ part, int
   }
 }
 
+// Synchronized BatchNorm: the row-tile partial sums [2][n_tiles][N] of this rank are reduced to [2][N] IN PLACE before the
+// exchange (fp64 accumulation in tile order, one thread per column: it reads all of its 2 n_tiles inputs before it writes the
+// two slots, which are inputs of that thread only), so the collective's length is 2 N whatever the rank's row count and tile
+// size -- ranks with different shard sizes exchange the same number of floats -- and the apply kernels read
+// n_tiles = 1.
+__global__ __launch_bounds__(256) void part_reduce_kernel(float* __restrict__ part, int n_tiles, int N) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= N) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int t = 0; t < n_tiles; ++t) {
+    s1 += (double)part[(size_t)t * N + col];
+    s2 += (double)part[((size_t)n_tiles + t) * N + col];
+  }
+  part[col] = (float)s1;
+  part[(size_t)N + col] = (float)s2;
+}
+
 struct BnFwdArgs {
   const float* a;  // [B][N] post-ReLU
   float* h;        // [B][N] out
@@ -1315,6 +1332,11 @@ static int train_fwd_bwd_impl(lipasr_mlp_t m, const float* params, float* bnstat
     if (LP_ON) {
       rc = launch_gemm(0, 1, g, st);
       if (rc != LIPASR_OK) return rc;
+      if (sa.seg >= 0 && !last && L.bn) {  // synchronized BatchNorm: [2][row tiles][N] -> [2][N] before the exchange
+        hipLaunchKernelGGL(part_reduce_kernel, dim3((L.n_out + 255) / 256), dim3(256), 0, st, part,
+                           stats_row_tiles(batch, L.n_out, L.n_in, m->lds_min_tiles), L.n_out);
+        LP_LAUNCH_CHECK();
+      }
     }
     if (!last && L.bn) ++cur;  // exchange point: the partial sums of a, a^2 are complete
     if (!last && L.offH != L.offA && LP_ON) {
@@ -1323,7 +1345,7 @@ static int train_fwd_bwd_impl(lipasr_mlp_t m, const float* params, float* bnstat
       b.a = ws + L.offA; b.h = ws + L.offH; b.B = batch; b.N = L.n_out; b.has_bn = L.bn ? 1 : 0;
       b.Bstat = bstat;
       b.part = part;
-      b.n_tiles = stats_row_tiles(batch, L.n_out, L.n_in, m->lds_min_tiles);
+      b.n_tiles = sa.seg >= 0 ? 1 : stats_row_tiles(batch, L.n_out, L.n_in, m->lds_min_tiles);
       if (L.bn) {
         b.gamma = params + L.offg; b.beta = params + L.offbe;
         b.mmean = bnstate + L.offmm; b.mvar = bnstate + L.offmv;
@@ -1365,6 +1387,11 @@ static int train_fwd_bwd_impl(lipasr_mlp_t m, const float* params, float* bnstat
     if (LP_ON) {
       rc = launch_gemm(0, 0, gx, st);
       if (rc != LIPASR_OK) return rc;
+      if (sa.seg >= 0 && P.bn) {
+        hipLaunchKernelGGL(part_reduce_kernel, dim3((P.n_out + 255) / 256), dim3(256), 0, st, part,
+                           stats_row_tiles(batch, P.n_out, L.n_out, m->lds_min_tiles), P.n_out);
+        LP_LAUNCH_CHECK();
+      }
     }
     if (P.bn) ++cur;  // exchange point: the partial sums of g, g xhat are complete
     if (P.bn && LP_ON) {
@@ -1373,7 +1400,7 @@ static int train_fwd_bwd_impl(lipasr_mlp_t m, const float* params, float* bnstat
       b.g = tmp; b.a = ws + P.offA; b.dz = ws + P.offDz; b.B = batch; b.N = P.n_out;
       b.Bstat = bstat; b.grad_scale = sa.grad_scale;
       b.part = part;
-      b.n_tiles = stats_row_tiles(batch, P.n_out, L.n_out, m->lds_min_tiles);
+      b.n_tiles = sa.seg >= 0 ? 1 : stats_row_tiles(batch, P.n_out, L.n_out, m->lds_min_tiles);
       b.gamma = params + P.offg; b.save_mean = ws + P.offMean;
       b.dgamma = grads + P.offg; b.dbeta = grads + P.offbe;
       const dim3 grid((P.n_out + 127) / 128, (batch + kApplyRows - 1) / kApplyRows);
@@ -1445,12 +1472,12 @@ int lipasr_mlp_train_segment_exchange(lipasr_mlp_t m, int batch, int seg, size_t
   int cur = 0;
   for (int l = 0; l + 1 < m->n_layers; ++l)  // forward: layer l's GEMM closes a segment if layer l has BatchNorm
     if (m->L[l].bn) {
-      if (cur == seg) { *floats = 2 * (size_t)stats_row_tiles(batch, m->L[l].n_out, m->L[l].n_in, m->lds_min_tiles) * m->L[l].n_out; return LIPASR_OK; }
+      if (cur == seg) { *floats = 2 * (size_t)m->L[l].n_out; return LIPASR_OK; }  // reduced to [2][N] by part_reduce_kernel
       ++cur;
     }
   for (int l = m->n_layers - 1; l >= 1; --l)  // backward: the dX GEMM into layer l-1 closes one if layer l-1 has BatchNorm
     if (m->L[l - 1].bn) {
-      if (cur == seg) { *floats = 2 * (size_t)stats_row_tiles(batch, m->L[l - 1].n_out, m->L[l].n_out, m->lds_min_tiles) * m->L[l - 1].n_out; return LIPASR_OK; }
+      if (cur == seg) { *floats = 2 * (size_t)m->L[l - 1].n_out; return LIPASR_OK; }
       ++cur;
     }
   return LIPASR_OK;

@@ -497,13 +497,8 @@ class Model:
                    C.byref(cfg), N.ptr(self._grads), N.ptr(self._loss_rows), N.ptr(self._correct_rows),
                    N.ptr(probs), N.stream_ptr()))
 
-    def train_fwd_bwd_syncbn(self, xb, yb, dp, global_batch, masks=None, dropout=True, probs=None):
-        """Synchronized BatchNorm (opt-in): the same kernels as train_fwd_bwd, run segment by segment with a SUM all-reduce
-        of the BatchNorm column partial sums between segments (``dp``: lipasr.parallel.DataParallel), so that every rank
-        normalises with the statistics of the GLOBAL batch, as the single-device reference does.  Eager (no HIP graph):
-        2 x (BatchNorm layers) small collectives per step."""
-        bsz = xb.shape[0]
-        cfg = self._dropout_cfg(masks, dropout)
+    def syncbn_segments(self):
+        """Number of segments the synchronized-BatchNorm step is cut into (allocates the partial-sum buffer on first use)."""
         if getattr(self, "_part", None) is None:
             n = N.sz()
             N.check(N.lib.lipasr_mlp_part_floats(self._plan, C.byref(n)))
@@ -511,15 +506,33 @@ class Model:
             ns = C.c_int()
             N.check(N.lib.lipasr_mlp_train_segments(self._plan, C.byref(ns)))
             self._n_segments = ns.value
-        for seg in range(self._n_segments):
-            N.check(N.lib.lipasr_mlp_train_segment(self._plan, seg, N.ptr(self._params), N.ptr(self._bnstate), N.ptr(xb), N.ptr(yb), bsz,
-                                                   1.0 / float(global_batch), C.byref(cfg), N.ptr(self._grads), N.ptr(self._loss_rows),
-                                                   N.ptr(self._correct_rows), N.ptr(probs), N.ptr(self._part), int(global_batch),
-                                                   1.0 / float(dp.world), N.stream_ptr()))
-            n = N.sz()
-            N.check(N.lib.lipasr_mlp_train_segment_exchange(self._plan, bsz, seg, C.byref(n)))
-            if n.value:
-                dp.allreduce_grads(self._part[:int(n.value)])
+        return self._n_segments
+
+    def syncbn_segment(self, seg, xb, yb, global_batch, world, masks=None, dropout=True, probs=None):
+        """Enqueue segment ``seg`` of the training step (it ends right after a GEMM whose epilogue left BatchNorm column sums,
+        reduced to [2][width] in self._part); returns the number of floats of self._part to SUM-all-reduce before the next
+        segment (0 after the last one).  The count does not depend on this rank's row count: uneven shards are fine."""
+        bsz = xb.shape[0]
+        cfg = self._dropout_cfg(masks, dropout)
+        self.syncbn_segments()
+        N.check(N.lib.lipasr_mlp_train_segment(self._plan, seg, N.ptr(self._params), N.ptr(self._bnstate), N.ptr(xb), N.ptr(yb), bsz,
+                                               1.0 / float(global_batch), C.byref(cfg), N.ptr(self._grads), N.ptr(self._loss_rows),
+                                               N.ptr(self._correct_rows), N.ptr(probs), N.ptr(self._part), int(global_batch),
+                                               1.0 / float(world), N.stream_ptr()))
+        n = N.sz()
+        N.check(N.lib.lipasr_mlp_train_segment_exchange(self._plan, bsz, seg, C.byref(n)))
+        return int(n.value)
+
+    def train_fwd_bwd_syncbn(self, xb, yb, dp, global_batch, masks=None, dropout=True, probs=None):
+        """Synchronized BatchNorm (opt-in): the same kernels as train_fwd_bwd, run segment by segment with a SUM all-reduce
+        of the BatchNorm column sums between segments (``dp``: lipasr.parallel.DataParallel), so that every rank
+        normalises with the statistics of the GLOBAL batch, as the single-device reference does: 2 x (BatchNorm layers)
+        small collectives per step (2 x width floats each, whatever the ranks' row counts).  TrainPipeline replays every
+        segment as a HIP graph."""
+        for seg in range(self.syncbn_segments()):
+            n = self.syncbn_segment(seg, xb, yb, global_batch, dp.world, masks=masks, dropout=dropout, probs=probs)
+            if n:
+                dp.allreduce_grads(self._part[:n])
 
     def train_dw0(self, xb):
         N.check(N.lib.lipasr_mlp_train_dw0(self._plan, N.ptr(xb), xb.shape[0], N.ptr(self._grads), N.stream_ptr()))

@@ -156,6 +156,11 @@ class TrainPipeline:
         # the three-kernel path's persistent resampler sizes its grid to one workgroup per CU it may use
         if hasattr(self.ex, "set"):
             self.ex.set(1, self.mfcc_cus)
+            if not self._custom_ex:
+                # On a CU share the STFT kernel's fused DCT epilogue (one workgroup per clip holds its 74 kB of LDS while two
+                # of its four wavefronts run the fp32 DCT) loses to the separate dct_kernel: stage 0.400 against 0.388 ms on
+                # 96 CUs, step 0.434 against 0.418 ms (round 4); alone on the whole chip it wins (0.124 against 0.138 ms)
+                self.ex.set(0, 512)
         # the classifier's stream on the CUs the MFCC stream does not use
         want = self._train_cus if self._train_cus != "auto" else os.environ.get("LIPASR_TRAIN_CUS", "all" if (self._custom_ex or self.pgd) else "rest")
         if want == "rest" and k < n_groups:
@@ -171,6 +176,7 @@ class TrainPipeline:
                 # on part of the chip the LDS-tiled GEMM pays from fewer tiles on (layer 2 forward, the dX GEMM into layer 2:
                 # 128 tiles): -16 us on the classifier's graph at 160 CUs (PGD, which keeps every CU, loses 8 % with it)
                 N.check(N.lib.lipasr_mlp_set_gemm_tiles(self.model._plan, 128))
+                self._gemm_tiles_set = True  # the pipeline owns this setting: close() puts the model's plan back
         return torch.cuda.ExternalStream(st.value, device=self.dev)
 
     # ---- pieces (all enqueue on the current stream)
@@ -186,6 +192,62 @@ class TrainPipeline:
                                                      float(self.pgd.get("eps_step", 0.1)), float(self.pgd["eps"]), N.stream_ptr()))
             x = xa
         m.train_fwd_bwd(x, y, inv_batch=1.0 / float(global_batch), defer_dw0=defer_dw0)
+
+    def _attack_only(self, bsz, b):
+        """The PGD inner loop alone (inference-mode BatchNorm: nothing to synchronise); returns the training input."""
+        m = self.model
+        x = self._feats2[b][:bsz]
+        if not self.pgd:
+            return x
+        y = self._labels2[b][:bsz]
+        xa = self.x_adv[:bsz]
+        xa.copy_(x)
+        for _ in range(int(self.pgd.get("max_iter", 20))):
+            N.check(N.lib.lipasr_mlp_attack_step(m._plan, N.ptr(m._params), N.ptr(m._bnstate), N.ptr(xa), N.ptr(x), N.ptr(y), bsz,
+                                                 float(self.pgd.get("eps_step", 0.1)), float(self.pgd["eps"]), N.stream_ptr()))
+        return xa
+
+    def _syncbn_step(self, bsz, b, gb):
+        """Synchronized BatchNorm: [PGD loop] -> segment 0 | all-reduce | segment 1 | ... | gradient all-reduce | update.
+        With graphs every piece between two collectives is one replayed HIP graph (the collectives themselves are eager
+        torch.distributed calls on the stream)."""
+        m = self.model
+        n_seg = m.syncbn_segments()
+        y = self._labels2[b][:bsz]
+        xin = (self.x_adv if self.pgd else self._feats2[b])[:bsz]
+        if not self.use_graph:
+            self._attack_only(bsz, b)
+            for seg in range(n_seg):
+                n = m.syncbn_segment(seg, xin, y, gb, self.dp.world)
+                if n:
+                    self.dp.allreduce_grads(m._part[:n])
+            self.dp.allreduce_grads(m._grads)
+            self._update()
+            return
+        key = (bsz, b, gb, "syncbn")
+        g = self._graphs.get(key)
+        if g is None:
+            counts = []
+
+            def first():
+                self._attack_only(bsz, b)
+                counts.append(m.syncbn_segment(0, xin, y, gb, self.dp.world))
+
+            ids = [self._capture(first)]
+            for seg in range(1, n_seg):
+                ids.append(self._capture(lambda s=seg: counts.append(m.syncbn_segment(s, xin, y, gb, self.dp.world))))
+            ids.append(self._capture(self._update))
+            self._sync_counts = getattr(self, "_sync_counts", {})
+            self._sync_counts[key] = counts
+            g = tuple(ids)
+            self._graphs[key] = g
+        counts = self._sync_counts[key]
+        for seg in range(n_seg):
+            N.check(N.lib.lipasr_graph_launch(self.h.h, g[seg], N.stream_ptr()))
+            if counts[seg]:
+                self.dp.allreduce_grads(m._part[:counts[seg]])
+        self.dp.allreduce_grads(m._grads)
+        N.check(N.lib.lipasr_graph_launch(self.h.h, g[n_seg], N.stream_ptr()))
 
     def _dw0(self, bsz, b):
         self.model.train_dw0((self.x_adv if self.pgd else self._feats2[b])[:bsz])
@@ -293,11 +355,7 @@ class TrainPipeline:
                 self._prof_i += 1
                 prof[0].record(self.stream)
             if self.sync_bn:
-                if self.pgd:
-                    raise NotImplementedError("sync_bn with the PGD inner loop")
-                self.model.train_fwd_bwd_syncbn(self._feats2[b][:bsz], self._labels2[b][:bsz], self.dp, gb)
-                self.dp.allreduce_grads(self.model._grads)
-                self._update()
+                self._syncbn_step(bsz, b, gb)
             elif not self.use_graph:
                 if self.dp.world == 1:
                     self._attack_and_train(bsz, b, gb)
@@ -362,6 +420,8 @@ class TrainPipeline:
         if not self.h.alive:  # the handle went first and took graphs and streams with it
             self._graphs.clear()
             self._masked_stream = self._masked_train_stream = None
+            # the ExternalStream wrappers point at destroyed queues: nothing may synchronise on them any more
+            self.stream = self.mfcc_stream = torch.cuda.current_stream(self.dev)
             return
         self.synchronize()
         for g in self._graphs.values():
@@ -378,6 +438,9 @@ class TrainPipeline:
             self._masked_train_stream = None
             self.stream = torch.cuda.Stream(device=self.dev)
             N.lib.lipasr_stream_destroy(self.h.h, st)
+        if getattr(self, "_gemm_tiles_set", False) and getattr(self.model, "_plan", None):
+            self._gemm_tiles_set = False
+            N.lib.lipasr_mlp_set_gemm_tiles(self.model._plan, 0)  # back to the library's default threshold
         if not self._custom_ex:
             self.ex.close()  # the pipeline's own MFCC plan
 

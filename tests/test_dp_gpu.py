@@ -272,3 +272,72 @@ def test_sync_batchnorm_two_ranks_match_one_rank(cuda, tmp_path):
     assert float(d_sync.quantile(0.999)) < 1e-4       # as tight as the no-BatchNorm parity test above
     assert float(bn_rep) > 10 * float(bn_sync)        # ... which per-replica statistics are not
     torch.testing.assert_close(r0[True]["norms"], pipe1.norms.cpu(), rtol=1e-3, atol=0)
+
+
+# ------------------------------------------------------------------ round 4: uneven shards and the PGD inner loop under synchronized BatchNorm
+def _sync_uneven_run(dp, split, pgd, steps=3):
+    """64 rows per step cut into `split` rows per rank (40 | 24 rows are 2 | 1 row tiles of 32: the partial-sum
+    buffers of the two ranks have different shapes; they are reduced to [2][width] before the exchange)."""
+    from helpers import build_model, dev, load_params
+    from lipasr.pipeline import TrainPipeline
+    from oracle import mlp_ref as P
+
+    spec = [P.LayerSpec(s.n_in, s.n_out, s.bn, 0.0, s.nonneg) for s in P.vd_constrained_spec()]
+    m = build_model(spec, max_batch=64)
+    load_params(m, P.init_params(spec, seed=8, dtype=np.float32, nonneg_init=True))
+    rng = np.random.default_rng(23)
+    x = dev(rng.standard_normal((64 * steps, 880)))
+    y = dev(P.to_categorical(rng.integers(0, 10, 64 * steps), 10))
+    lo = sum(split[:dp.rank]) if dp.world > 1 else 0
+    n = split[dp.rank] if dp.world > 1 else 64
+    pipe = TrainPipeline(m, batch=max(split) if dp.world > 1 else 64, rho=0.1, constraint="product", dp=dp, use_graph=True, sync_bn=True,
+                         pgd=dict(eps=0.3, eps_step=0.1, max_iter=3) if pgd else None)
+    for s in range(steps):
+        xb, yb = x[64 * s + lo:64 * s + lo + n], y[64 * s + lo:64 * s + lo + n]
+        pipe.step(None, yb.contiguous(), features=xb.contiguous(), global_batch=64)
+    pipe.synchronize()
+    return m, pipe
+
+
+def _sync_uneven_worker(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "asr-using-robust-nn_amd"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from lipasr.parallel import DataParallel, init_from_env
+
+    torch.cuda.set_device(0)
+    init_from_env("gloo")
+    dp = DataParallel()
+    out = {}
+    for pgd in (False, True):
+        m, pipe = _sync_uneven_run(dp, (40, 24), pgd)
+        out[pgd] = {"params": m._params.cpu(), "bn": m._bnstate.cpu(), "div": dp.max_divergence(m._params)}
+        pipe.close()
+    torch.save(out, os.path.join(out_dir, f"u{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_sync_batchnorm_uneven_shards_and_pgd(cuda, tmp_path):
+    """Synchronized BatchNorm with shards of 40 and 24 rows (different row-tile counts per rank) and, second, with the PGD
+    inner loop in front of the step (it raised NotImplementedError): both reproduce the single-process
+    run of the 64-row batch, every piece between two collectives replayed as a HIP graph."""
+    import torch.multiprocessing as mp
+    from lipasr.parallel import DataParallel
+
+    ref = {}
+    for pgd in (False, True):
+        m1, pipe1 = _sync_uneven_run(DataParallel(), (64,), pgd)
+        ref[pgd] = (m1._params.cpu(), m1._bnstate.cpu())
+        pipe1.close()
+    mp.spawn(_sync_uneven_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(os.path.join(tmp_path, "u0.pt")), torch.load(os.path.join(tmp_path, "u1.pt"))
+    for pgd in (False, True):
+        assert r0[pgd]["div"] == 0.0 and r1[pgd]["div"] == 0.0
+        assert torch.equal(r0[pgd]["bn"], r1[pgd]["bn"])
+        p_ref, bn_ref = ref[pgd]
+        d = ((r0[pgd]["params"] - p_ref).abs() / p_ref.abs().max()).quantile(0.999)
+        dbn = (r0[pgd]["bn"] - bn_ref).abs().max() / bn_ref.abs().max()
+        print(f"\nSyncBN 40|24 rows, pgd={pgd}: params q999 {float(d):.2e}, moving stats {float(dbn):.2e}")
+        assert float(dbn) < 1e-5 and float(d) < 1e-4
