@@ -56,6 +56,7 @@ class DataParallel:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self._timing = None  # time_collectives(): [(start, stop)] per gradient all-reduce
 
     def shard(self, *tensors):
         """This rank's contiguous slice of each global-batch tensor."""
@@ -79,8 +80,58 @@ class DataParallel:
         # gloo cannot reduce device tensors: used only by the single-GPU rehearsal of the DP path (tests)
         return t.is_cuda and dist.get_backend(self.group) == "gloo"
 
+    def time_collectives(self, on=True):
+        """Bracket every following allreduce_grads() with timestamps (HIP events on the current stream for device tensors,
+        the host clock otherwise); ``collective_ms()`` returns their mean.  bench.py turns this on for its untimed
+        profiling steps: how long the exchange is, and so how much of the step it exposes (it is not overlapped)."""
+        self._timing = [] if on else None
+
+    def collective_ms(self):
+        t = self._timing or []
+        self._timing = None
+        if not t:
+            return None
+        if isinstance(t[0][0], float):
+            return 1e3 * sum(b - a for a, b in t) / len(t)
+        t[-1][1].synchronize()
+        return sum(a.elapsed_time(b) for a, b in t) / len(t)
+
+    def probe(self, device):
+        """What the communicator really spans: the SUM over ranks of a tensor of ones (= the number of ranks the backend
+        reduced over, which is not WORLD_SIZE echoed back), the backend's name and, for RCCL, its version."""
+        info = {"world_size_env": self.world, "backend": dist.get_backend(self.group) if dist.is_initialized() else None, "ranks_seen": 1,
+                "rccl_version": None}
+        if self.world > 1:
+            t = torch.ones(8, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            info["ranks_seen"] = int(round(float(t[0].item())))
+            assert bool((t == t[0]).all())
+            if info["backend"] == "nccl":
+                try:
+                    info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+                except Exception:
+                    pass
+        return info
+
     def allreduce_grads(self, flat):
         """The one collective of a step: in-place SUM over the flat gradient buffer."""
+        if self._timing is not None and self.world > 1:
+            import time
+
+            if flat.is_cuda:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                self._allreduce(flat)
+                e1.record()
+                self._timing.append((e0, e1))
+            else:
+                t0 = time.perf_counter()
+                self._allreduce(flat)
+                self._timing.append((t0, time.perf_counter()))
+            return flat
+        return self._allreduce(flat)
+
+    def _allreduce(self, flat):
         if self.world > 1:
             if self._host_staged(flat):
                 tmp = flat.cpu()

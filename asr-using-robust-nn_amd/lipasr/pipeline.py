@@ -177,6 +177,20 @@ class TrainPipeline:
                 # 128 tiles): -16 us on the classifier's graph at 160 CUs (PGD, which keeps every CU, loses 8 % with it)
                 N.check(N.lib.lipasr_mlp_set_gemm_tiles(self.model._plan, 128))
                 self._gemm_tiles_set = True  # the pipeline owns this setting: close() puts the model's plan back
+        elif os.environ.get("LIPASR_TRAIN_OWN_QUEUE", "1") == "1":
+            # The classifier keeps every CU (PGD, custom extractor, train_cus="all") -- but NOT on a stream of torch's pool: pool
+            # streams are multiplexed over GPU_MAX_HW_QUEUES (4) hardware queues, and once enough streams exist in the process the
+            # training stream can land on the queue that carries the MFCC stream's kernels; its 440-node PGD graph then waited
+            # behind them node by node: 13.0 ms per step instead of 4.1 as the fifth configuration of one process (round 3's
+            # unexplained 3x; round 4: scratch/pgd_fifth_probe.py, gone with GPU_MAX_HW_QUEUES=8).  A stream made with a FULL CU
+            # mask owns a hardware queue like the two partition streams do.
+            mask2 = (C.c_uint32 * words)()
+            for b in range(n_cu):
+                mask2[b // 32] |= 1 << (b % 32)
+            st2 = N.c_s()
+            if N.lib.lipasr_stream_create_masked(self.h.h, mask2, words, C.byref(st2)) == N.OK:
+                self._masked_train_stream = st2
+                self.stream = torch.cuda.ExternalStream(st2.value, device=self.dev)
         return torch.cuda.ExternalStream(st.value, device=self.dev)
 
     # ---- pieces (all enqueue on the current stream)

@@ -82,8 +82,9 @@ def cpu_baseline(batch, warmup=5, steps=20):
     spec = P.vd_constrained_spec()
     p = P.init_params(spec, seed=0, dtype=np.float32, nonneg_init=True)
     st = P.AdamState()
-    M.compute_mfcc_batch(waves[:2], fast=True)  # builds the cached tables before the fork
-    ctx = mp.get_context("fork")
+    # spawn, not fork: this process holds a HIP context by now (tests/helpers.py states the same rule); every worker builds
+    # its own tables in the warm-up map below
+    ctx = mp.get_context("spawn")
     t_total, t_mfcc = 0.0, 0.0
     with ctx.Pool(cores, initializer=_cpu_worker_init) as pool:
         pool.map(_cpu_mfcc_chunk, [waves[i:i + 1] for i in range(cores)])  # every worker has imported and built its tables
@@ -106,6 +107,23 @@ def cpu_baseline(batch, warmup=5, steps=20):
             "sample": f"{steps} timed steps of batch {batch} after {warmup} warm-up steps ({t_total:.1f} s; oracle: NumPy MFCC loop over {cores} "
                       f"processes, fp32 NumPy/OpenBLAS train step, simple_norm_constraint with LAPACK SVD); {t_mfcc / t_total:.0%} of the time in MFCC",
             "label": "reference-equivalent CPU path (restated; TensorFlow/librosa unavailable offline)"}
+
+
+# rocprofv3 names of the three timed MFCC slots (what `roofline.dominant_kernel` must match in profiles/*kernel_stats.csv)
+MFCC_KERNELS = {"resample": "resample_persist_h2_kernel", "stft_mel": "stft_bdft_kernel", "dct": "dct_kernel"}
+MFCC_SOURCES = ("mfcc.hip", "stft_bdft.hip", "stft.h", "mfcc_tables.h")
+
+
+def mfcc_source_sha():
+    """sha256 over the MFCC kernel sources: profiles/r04_mfcc_pmc.json records the value its counters were taken at, and the
+    bench line says `traffic_stale: true` when the sources have changed since."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for name in MFCC_SOURCES:
+        with open(os.path.join(ROOT, "asr-using-robust-nn_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 POOL_CLIPS = 65536                      # SURVEY 8(d): throughput runs loop a resident pool of >= 65 536 clips per GPU (4.2 GB)
@@ -146,6 +164,7 @@ def run_config(opt, pool, batch, rank, world, device, steps, warmup, profile):
     feats = torch.cat([ex(waves[i * batch:(i + 1) * batch]) for i in range(min(4, n_batches))])
     sc = StandardScaler().fit(feats)
     dp = DataParallel()
+    comm = dp.probe(device)
     if world > 1:
         dp.broadcast(sc.mean_, sc.scale_, model._params, model._bnstate)
     pgd = dict(eps=opt.get("pgd_eps", 0.5), eps_step=0.1, max_iter=opt["pgd"]) if opt.get("pgd", 0) > 0 else None
@@ -225,10 +244,13 @@ def run_config(opt, pool, batch, rank, world, device, steps, warmup, profile):
     # steps after the measured region, so that the two event records per step do not touch `value`)
     n_prof = min(20, steps)
     pipe.profile_train(n_prof)
+    dp.time_collectives(True)  # HIP events around the gradient all-reduce of these untimed steps
     for i in range(n_prof):
         one(warmup + steps + i)
     pipe.synchronize()
     extras["train_graph_ms"] = pipe.train_ms()
+    extras["allreduce_ms"] = dp.collective_ms()
+    extras["comm"] = comm
     extras["mfcc_standalone_ms"] = standalone
     extras["mfcc_cus"] = getattr(pipe, "mfcc_cus", None)
     extras["train_cus"] = getattr(pipe, "train_cus", None)
@@ -242,24 +264,91 @@ def run_config(opt, pool, batch, rank, world, device, steps, warmup, profile):
     return dt, extras
 
 
-def _short(flags, batch, steps, warmup):
-    """One secondary single-GPU configuration, measured in a CHILD process (this script with `flags`): a configuration
-    that shares the process with earlier ones inherits their streams and hardware queues -- the PGD-20 graph of ~440
-    kernel nodes replayed 3x slower as the fifth configuration of one process than alone (12.5 vs 4.2 ms, round 3)."""
-    import subprocess
+def run_config_dry(batch, rank, world, steps, warmup):
+    """--dry-run-dp: this script's world > 1 control flow on the CPU with the gloo backend and a stand-in replica (a two-layer
+    torch classifier on random features; NOT the product and NOT a measurement): communicator probe, broadcast of scaler and
+    start state from rank 0, per-step shard -> fwd/bwd -> lipasr.parallel.DataParallel gradient all-reduce -> update, the
+    barrier + MAX-over-ranks timing, the JSON line's data-parallel fields.  tests/test_dp_gloo.py runs it under
+    torch.distributed.run --nproc-per-node 2, so the branches an 8-GPU node takes first are rehearsed here."""
+    import torch.distributed as dist
 
-    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps), "--warmup", str(warmup), "--batch-per-gpu", str(batch),
-           "--pool-clips", str(16 * batch), "--skip-cpu-baseline", "--skip-b512", "--skip-other-configs"] + flags
-    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK=os.environ.get("LOCAL_RANK", "0"))
+    from lipasr.parallel import DataParallel
+
+    class Replica:
+        def __init__(self, seed):
+            g = torch.Generator().manual_seed(seed)
+            self.w = [torch.randn(880, 64, generator=g) * 0.03, torch.zeros(64), torch.randn(64, 10, generator=g) * 0.1, torch.zeros(10)]
+            self.n = sum(t.numel() for t in self.w)
+            self.params = torch.cat([t.reshape(-1) for t in self.w])
+            self.grads = torch.zeros(self.n)
+
+        def _views(self):
+            o, out = 0, []
+            for t in self.w:
+                out.append(self.params[o:o + t.numel()].view_as(t))
+                o += t.numel()
+            return out
+
+        def train_fwd_bwd(self, x, y, inv_batch=None, **kw):
+            w1, b1, w2, b2 = [v.clone().requires_grad_(True) for v in self._views()]
+            logits = torch.relu(x @ w1 + b1) @ w2 + b2
+            loss = -(y * torch.log_softmax(logits, 1)).sum() * inv_batch
+            gs = torch.autograd.grad(loss, [w1, b1, w2, b2])
+            self.grads.copy_(torch.cat([g.reshape(-1) for g in gs]))
+            self.loss = float(loss.detach())
+
+        def apply_adam(self):
+            self.params.sub_(0.05 * self.grads)
+
+    dp = DataParallel()
+    comm = dp.probe("cpu")
+    rep = Replica(seed=100 + rank)  # replicas START different: the broadcast must bring them together
+    g = torch.Generator().manual_seed(7)
+    pool_x = torch.randn(8 * batch * world, 880, generator=g)
+    pool_y = torch.nn.functional.one_hot(torch.randint(0, 10, (8 * batch * world,), generator=g), 10).float()
+    mean, scale = pool_x.mean(0), pool_x.std(0)
+    if rank != 0:
+        mean, scale = torch.zeros_like(mean), torch.ones_like(scale)
+    dp.broadcast(mean, scale, rep.params)
+
+    def one(i):
+        s = (i % 8) * batch * world
+        xb, yb = dp.shard(pool_x[s:s + batch * world], pool_y[s:s + batch * world])
+        dp.train_step(rep, (xb - mean) / scale, yb, global_batch=batch * world)
+
+    for i in range(warmup):
+        one(i)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        one(warmup + i)
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    dp.time_collectives(True)
+    for i in range(min(5, steps)):
+        one(warmup + steps + i)
+    return dt, {"comm": comm, "allreduce_ms": dp.collective_ms(), "loss": rep.loss, "divergence": dp.max_divergence(rep.params)}
+
+
+def _short(opt_over, pool, batch, device, steps, warmup):
+    """One secondary single-GPU configuration, measured IN THIS PROCESS after the headline (its own model + pipeline on the same
+    resident pool).  Round 3 ran these in child processes because the PGD-20 graph replayed 3x slower as the fifth configuration
+    of one process; the cause was the training stream sharing a hardware queue (torch pool streams are multiplexed over 4) --
+    TrainPipeline now gives it a queue of its own (scratch/pgd_fifth_probe.py: 4.07 ms as the fifth configuration,
+    4.09 alone)."""
+    opt = {"constraint": "product", "pgd": 0, "pgd_eps": 0.5, "bf16": False, "pre_extracted": False, "no_graph": False, "int16": False}
+    opt.update(opt_over)
     try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
-        d = json.loads(r.stdout.strip().splitlines()[-1])
+        sub = (pool[0][:16 * batch], pool[1][:16 * batch])
+        dt, ex = run_config(opt, sub, batch, 0, 1, device, steps, warmup, profile=True)
     except Exception as e:  # the headline must not die with a secondary record
         return {"error": f"{type(e).__name__}: {e}"[:200]}
-    rec = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "per_gpu_batch": batch, "steps": steps,
-           "dtype": "bf16 operands, f32 accumulate" if "--bf16" in flags else "f32", "train_graph_ms": d.get("train_graph_ms"),
-           "classifier_tflops": d.get("classifier_tflops"), "mfcc_stream": d.get("mfcc_stream"), "measured_in": "child process"}
-    return rec
+    cls = TRAIN_FLOP_PER_UTT * batch / (ex["train_graph_ms"] * 1e-3) / 1e12 if not opt["pgd"] and ex["train_graph_ms"] > 0 else None
+    return {"value": round(batch * steps / dt, 1), "unit": "utterances/sec", "ms_per_step": round(dt / steps * 1e3, 4), "per_gpu_batch": batch, "steps": steps,
+            "dtype": "bf16 operands, f32 accumulate" if opt["bf16"] else "f32", "train_graph_ms": round(ex["train_graph_ms"], 4),
+            "classifier_tflops": round(cls, 2) if cls else None, "mfcc_stream": ex.get("mfcc_stream"), "measured_in": "this process"}
 
 
 def run_fit_api(device, batch=512, n=16384, epochs=3):
@@ -309,6 +398,7 @@ def main():
     ap.add_argument("--int16", action="store_true", help="the resident pool as 16-bit PCM (what the corpus is): 2 bytes per sample in, scaled by 2^-15 on the device")
     ap.add_argument("--fit-api", action="store_true", help="only time the Keras-shaped fit() entry (used by the main run as a child process)")
     ap.add_argument("--skip-other-configs", action="store_true", help="do not add the config 2 / config 2 bf16 / config 5 records (N = 1 only)")
+    ap.add_argument("--dry-run-dp", action="store_true", help="rehearse the world > 1 control flow on the CPU (gloo, stand-in replica); prints a line marked dry_run, not a measurement")
     args = ap.parse_args()
     opt = {"constraint": None if args.constraint == "none" else args.constraint, "pgd": args.pgd, "pgd_eps": args.pgd_eps, "bf16": args.bf16,
            "pre_extracted": args.pre_extracted, "no_graph": args.no_graph, "int16": args.int16}
@@ -318,6 +408,26 @@ def main():
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     if world_env != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_env}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.dry_run_dp:
+        import torch.distributed as dist
+
+        rank, world = init_from_env("gloo")
+        dt, ex = run_config_dry(min(args.batch_per_gpu, 64), rank, world, args.steps, args.warmup)
+        t = torch.tensor([dt], dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            gb = min(args.batch_per_gpu, 64) * world
+            print(json.dumps({"dry_run": True, "metric": "utterances/sec (DRY RUN: CPU stand-in replica over gloo, not a measurement)",
+                              "value": round(gb * args.steps / float(t.item()), 1), "unit": "utterances/sec", "n_gpus": world, "steps": args.steps,
+                              "warmup": args.warmup, "ms_per_step": round(float(t.item()) / args.steps * 1e3, 4), "scaling": "weak",
+                              "rccl_ranks_seen": ex["comm"]["ranks_seen"], "rccl_version": ex["comm"]["rccl_version"], "comm_backend": ex["comm"]["backend"],
+                              "allreduce_ms": round(ex["allreduce_ms"], 4) if ex["allreduce_ms"] is not None else None,
+                              "replica_divergence": ex["divergence"], "loss": round(ex["loss"], 4),
+                              "config": {"global_batch": gb, "parallelism": f"dp{world}"}}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     rank, world = init_from_env("nccl" if world_env > 1 else None)
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
@@ -349,11 +459,12 @@ def main():
     # HBM traffic of the stage per launch: PMC counters cannot be read from inside this process, so the value is
     # the committed rocprofv3 measurement of the same kernels (separate --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH
     # doubled per MI355X_MICROARCH.md), scaled to this batch.
-    traffic, traffic_src, traffic_fused = None, None, None
-    for name in ("r03_mfcc_pmc.json", "r02_mfcc_pmc.json"):
+    traffic, traffic_src, traffic_fused, traffic_stale = None, None, None, None
+    for name in ("r04_mfcc_pmc.json", "r03_mfcc_pmc.json", "r02_mfcc_pmc.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 eor = json.load(f)["end_of_round"]
+            traffic_stale = eor.get("source_sha16") != mfcc_source_sha()  # (files before round 4 carry no hash: stale)
             key = "fused_stage_bytes_per_utt" if ex.get("mfcc_fused") and "fused_stage_bytes_per_utt" in eor else "stage_bytes_per_utt"
             traffic = round(eor[key] * batch)
             if "fused_stage_bytes_per_utt" in eor:
@@ -365,9 +476,12 @@ def main():
     if args.int16:  # the committed counter passes ran on float32 clips
         traffic, traffic_src, traffic_fused = None, None, None
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": traffic, "traffic_source": traffic_src,
-                "stage": "MFCC (K1 = mfcc_fused_kernel [resample + STFT + mel + dB, timed in the stft_mel slot] + dct_kernel)" if ex.get("mfcc_fused") else "MFCC (K1 = resample + stft_mel + dct kernels)",
-                "dominant_kernel": ("mfcc_fused" if ex.get("mfcc_fused") and dom == "stft_mel" else dom) + "_kernel",
+                "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale,
+                "stage": "MFCC (K1 = mfcc_fused_kernel [resample + STFT + mel + dB, timed in the stft_mel slot] + dct_kernel)" if ex.get("mfcc_fused") else
+                         "MFCC (K1 = resample_persist_h2_kernel + stft_bdft_kernel [block-DFT STFT on the matrix pipe + mel + dB] + dct_kernel)",
+                "dominant_kernel": "mfcc_fused_kernel" if ex.get("mfcc_fused") and dom == "stft_mel" else
+                                   ("stft_mel2_kernel" if dom == "stft_mel" and (int(os.environ.get("LIPASR_MFCC_MASK", "0")) & 256) else MFCC_KERNELS[dom]),
+                "kernel_names": MFCC_KERNELS,
                 "algorithmic_bytes_per_utt": bytes_per_utt, "units_per_launch": batch,
                 "kernel_ms": {k: round(ms[k], 4) for k in ("resample", "stft_mel", "dct")},
                 "fp32_flop_frac": round(MFCC_FLOP_PER_UTT * batch / (stage_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 5) if stage_ms > 0 else 0.0,
@@ -408,7 +522,13 @@ def main():
            # stream while the next batch's MFCC runs on its own stream; TFLOP/s = 9.59 MFLOP/utt x batch / that time
            "train_graph_ms": round(ex["train_graph_ms"], 4), "classifier_tflops": round(cls_tflops, 2) if cls_tflops else None,
            "classifier_fp32_mfma_frac": round(cls_tflops / FP32_PEAK_TFLOPS, 4) if cls_tflops else None,
-           "event_ms_per_step": round(ex["event_ms_per_step"], 4), "final_product_norm": ex["final_norm"], "loss": round(ex["loss"], 4)}
+           "event_ms_per_step": round(ex["event_ms_per_step"], 4), "final_product_norm": ex["final_norm"], "loss": round(ex["loss"], 4),
+           # data parallel: how many ranks the collective backend really reduced over (SUM of ones, not WORLD_SIZE echoed), its
+           # version, the gradient all-reduce's duration (HIP events, untimed extra steps) and the share of the classifier's part
+           # of the step it exposes (the exchange is not overlapped: DESIGN.md 5)
+           "rccl_ranks_seen": ex["comm"]["ranks_seen"], "rccl_version": ex["comm"]["rccl_version"], "comm_backend": ex["comm"]["backend"],
+           "allreduce_ms": round(ex["allreduce_ms"], 4) if ex.get("allreduce_ms") is not None else None,
+           "allreduce_exposed_frac": round(ex["allreduce_ms"] / ex["train_graph_ms"], 4) if ex.get("allreduce_ms") and ex["train_graph_ms"] > 0 else None}
     if world == 1 and not args.skip_b512 and batch != 512:
         dt5, ex5 = run_config(opt, pool, 512, rank, world, device, args.steps, args.warmup, profile=True)
         out["reference_batch_512"] = {"value": round(512 * args.steps / dt5, 1), "ms_per_step": round(dt5 / args.steps * 1e3, 4),
@@ -417,19 +537,15 @@ def main():
     if world == 1 and not args.skip_other_configs and not (args.pgd or args.pre_extracted or args.bf16):
         # the other single-GPU BASELINE configurations, in the driver-run record (short runs; each is its own model + pipeline)
         k, w = min(args.steps, 50), min(args.warmup, 10)
+        out["reference_config_2_pre_extracted_f32"] = _short({"pre_extracted": True}, pool, batch, device, k, w)
+        out["reference_config_2_pre_extracted_bf16"] = _short({"pre_extracted": True, "bf16": True}, pool, batch, device, k, w)
+        out["reference_config_5_pgd20_1gpu"] = _short({"pgd": 20, "pgd_eps": 0.5}, pool, batch, device, min(k, 20), min(w, 5))
+        # config 3 on 16-bit PCM clips (SURVEY 8d's 35 520 B/utt variant): the resampler reads int16 directly
+        out["reference_config_3_int16_pcm_input"] = _short({"int16": True}, pool, batch, device, k, w)
         del pool
         torch.cuda.empty_cache()
-        out["reference_config_2_pre_extracted_f32"] = _short(["--pre-extracted"], batch, k, w)
-        out["reference_config_2_pre_extracted_bf16"] = _short(["--pre-extracted", "--bf16"], batch, k, w)
-        out["reference_config_5_pgd20_1gpu"] = _short(["--pgd", "20", "--pgd-eps", "0.5"], batch, min(k, 20), min(w, 5))
-        # config 3 on 16-bit PCM clips (SURVEY 8d's 35 520 B/utt variant): the resampler reads int16 directly
-        out["reference_config_3_int16_pcm_input"] = _short(["--int16"], batch, k, w)
         try:  # the Keras-shaped fit() entry with the constraint as a callback, as train_constraints.py drives it
-            import subprocess
-
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", "1", "--fit-api"], capture_output=True, text=True, timeout=300,
-                               env=dict(os.environ, WORLD_SIZE="1", RANK="0"))
-            out["reference_fit_api_batch_512"] = dict(json.loads(r.stdout.strip().splitlines()[-1]), measured_in="child process")
+            out["reference_fit_api_batch_512"] = dict(run_fit_api(device), measured_in="this process")
         except Exception as e:
             out["reference_fit_api_batch_512"] = {"error": f"{type(e).__name__}: {e}"[:200]}
         pool = None
