@@ -174,11 +174,14 @@ int lipasr_stream_destroy(lipasr_handle_t h, lipasr_stream_t stream) {
   DeviceGuard g(h->device);
   hipStream_t st = static_cast<hipStream_t>(stream);
   bool mine = false;
-  for (hipStream_t& s : h->streams)
-    if (s == st) { s = nullptr; mine = true; }
+  for (hipStream_t s : h->streams) mine = mine || s == st;
   LP_CHECK_ARG(mine, "lipasr_stream_destroy: not a live stream of this handle");
+  // the registry slot is cleared only once the queue is really gone: if either call fails the stream stays registered and
+  // lipasr_destroy retries it, instead of leaving a hardware queue to the runtime's static destructors
   LP_HIP(hipStreamSynchronize(st));
   LP_HIP(hipStreamDestroy(st));
+  for (hipStream_t& s : h->streams)
+    if (s == st) s = nullptr;
   return LIPASR_OK;
 }
 

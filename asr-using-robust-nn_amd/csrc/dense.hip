@@ -624,7 +624,7 @@ static int launch_gemm_group_tn(const GemmArgs* gs, int n, hipStream_t st) {
     grp.tile_start[k] = tiles;
     if (lds_tiles) {
       constexpr size_t lds_b = lds_gemm_bytes(kLdsBKMax);
-      static bool attr_set = false;
+      static bool attr_set_dev[16] = {}; int attr_dev = 0; (void)hipGetDevice(&attr_dev); bool& attr_set = attr_set_dev[attr_dev & 15];  /* per device */
       if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_lds_grouped_kernel<1, 1, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
@@ -662,7 +662,7 @@ template <int AMODE, int BMODE, int NW, bool BF>
 static void launch_gemm_tb(const GemmArgs& g, hipStream_t st) {
   const dim3 grid((g.N + 31) / 32, (g.M + 31) / 32);
   const size_t lds = (size_t)(NW * 32 * 32 + 4 * 8 * 8) * sizeof(float);
-  static bool attr_set = false;
+  static bool attr_set_dev[16] = {}; int attr_dev = 0; (void)hipGetDevice(&attr_dev); bool& attr_set = attr_set_dev[attr_dev & 15];  /* per device */
   if (lds > 48 * 1024 && !attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<AMODE, BMODE, NW, BF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -696,7 +696,7 @@ static int launch_gemm(int amode, int bmode, const GemmArgs& g, hipStream_t st) 
     constexpr size_t lds_b = lds_gemm_bytes(kLdsBKMax);
 #define LP_LDS(A_, B_)                                                                              \
   {                                                                                                 \
-    static bool attr_set = false;                                                                   \
+    static bool attr_set_dev[16] = {}; int attr_dev = 0; (void)hipGetDevice(&attr_dev); bool& attr_set = attr_set_dev[attr_dev & 15];  /* per device */                                                                   \
     if (!attr_set) {                                                                                \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_lds_kernel<A_, B_, true>),       \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);            \

@@ -1780,7 +1780,7 @@ static int launch_resample(const MfccPlan* p, const void* wav_any, int fmt, cons
       32 * ((kRsStride - 1) / 4) <= 5 * 64 * n_waves) {
     // persistent fp32 form (the parity reference of the fp16-plane kernel): one workgroup per CU-sized share of the work
     const size_t lds = (size_t)2 * 32 * kRsStride * sizeof(float);
-    static bool attr_set = false;
+    static bool attr_set_dev[16] = {}; int attr_dev = 0; (void)hipGetDevice(&attr_dev); bool& attr_set = attr_set_dev[attr_dev & 15];  /* per device */
     if (!attr_set) {
       LP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(resample_persist_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1794,7 +1794,7 @@ static int launch_resample(const MfccPlan* p, const void* wav_any, int fmt, cons
                        p->n_valid, p->n_y, p->up, p->down, p->left, nq, tiles, p->d_hband, p->d_lo);
   } else if (p->d_hband && !(p->stage_mask & 4)) {
     const size_t lds = (size_t)32 * kRsStride * sizeof(float);
-    static bool attr_set = false;
+    static bool attr_set_dev[16] = {}; int attr_dev = 0; (void)hipGetDevice(&attr_dev); bool& attr_set = attr_set_dev[attr_dev & 15];  /* per device */
     if (!attr_set) {
       LP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(resample_mfma_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1856,7 +1856,7 @@ static int launch_fused(const MfccPlan* p, const void* wav, int fmt, const int* 
   a.groups = reinterpret_cast<const int4*>(p->d_groups); a.n_groups = p->n_groups;
   fill_stft_args(p, nullptr, &a.st);
   const size_t lds = (size_t)kFuLdsFloats * sizeof(float);
-  static bool attr_set = false;
+  static bool attr_set_dev[16] = {}; int attr_dev = 0; (void)hipGetDevice(&attr_dev); bool& attr_set = attr_set_dev[attr_dev & 15];  /* per device */
   if (!attr_set) {
     LP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mfcc_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     LP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mfcc_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -236,7 +236,17 @@ class Handle:
         return bool(self.h)
 
     def close(self):
+        """Closes every live owner made on this handle first (pipelines, models, extractors, newest first): lipasr_destroy frees
+        their native plans, and an owner that still held a plan pointer would turn its next call into a use-after-free instead
+        of an error.  Closed owners raise on use."""
         if self.h:
+            for ref in reversed(list(_owners)):
+                obj = ref()
+                if obj is not None and (getattr(obj, "h", None) is self or getattr(obj, "_h", None) is self):
+                    try:
+                        obj.close()
+                    except Exception:
+                        pass
             lib.lipasr_destroy(self.h)
             self.h = None
 

@@ -91,3 +91,44 @@ def test_finaliser_during_capture_does_not_break_it(cuda):
     pipe.synchronize()
     pipe.close()
     m.close()
+
+
+def test_handle_close_closes_its_owners(cuda):
+    """lipasr_destroy frees every plan made on the handle; Handle.close() therefore closes the Python owners first
+    (newest first), so that a model / extractor / pipeline used afterwards raises instead of handing a freed plan to the
+    library.  In a child process: it ends this process's handle."""
+    code = r'''
+import sys, os
+R = sys.argv[1]
+for p in (R, os.path.join(R, "asr-using-robust-nn_amd"), os.path.join(R, "tests")):
+    sys.path.insert(0, p)
+import numpy as np, torch
+import lipasr._native as N
+from helpers import build_model, dev
+from lipasr.extract_features_construct_dataset import MfccExtractor
+from lipasr.pipeline import TrainPipeline
+from lipasr.synth import synth_clips
+from oracle import mlp_ref as P
+spec = P.vd_constrained_spec()
+m = build_model(spec, max_batch=32)
+ex = MfccExtractor(16000, 16000, 8)
+waves, labels = synth_clips(32, seed=7)
+pipe = TrainPipeline(m, batch=32, rho=0.1, use_graph=True)
+pipe.step(dev(waves), dev(P.to_categorical(labels, 10))); pipe.synchronize()
+N.get_handle(0).close()
+assert m._plan is None and ex._plan is None and pipe._closed
+for call in (lambda: ex(dev(waves[:8])), lambda: pipe.step(dev(waves), dev(P.to_categorical(labels, 10))),
+             lambda: m.train_fwd_bwd(torch.zeros(8, 880, device="cuda"), torch.zeros(8, 10, device="cuda"))):
+    try:
+        call()
+    except (RuntimeError, ValueError):
+        continue
+    raise SystemExit("a closed owner accepted a call")
+pipe.synchronize()  # the wrappers of the destroyed queues were replaced
+m2 = build_model(spec, max_batch=32)  # a fresh handle serves new owners
+ex2 = MfccExtractor(16000, 16000, 8)
+assert torch.isfinite(ex2(dev(waves[:8]))).all()
+print("handle_close: ok")
+'''
+    r = subprocess.run([sys.executable, "-c", code, ROOT], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "handle_close: ok" in r.stdout, (r.returncode, r.stdout[-1500:], r.stderr[-2500:])
