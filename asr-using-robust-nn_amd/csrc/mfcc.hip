@@ -70,6 +70,9 @@ struct MfccPlan {
   // kernel stft_mel2_kernel instead (the parity reference)
   BdftTables bd;
   int bd_seg = 44;  // frames per workgroup (a multiple of 4; 44 = a whole 1-s clip)
+  // the kernel's fused top_db + DCT epilogue (lipasr_mfcc_plan_set key 4): off by default -- measured on batches that are not
+  // cache-warm it loses to the separate dct_kernel (STFT 139 + 5 us against 120 + 19 us per 1024 clips, round 4)
+  bool bd_fuse_dct = false;
 };
 
 void mfcc_plan_free(MfccPlan* p) {
@@ -1892,8 +1895,8 @@ static int launch_from_22k(const MfccPlan* p, const float* y, const int* n_valid
                                  (int)dl));
     hipLaunchKernelGGL(dft_mel_kernel, dim3((d.total_rows + kDftRows - 1) / kDftRows), dim3(64 * p->dft_tiles), dl, st, d);
   } else if (stft2_ok(p) && p->bd.cfrag && !(p->stage_mask & 256)) {
-    // one workgroup per clip: the kernel finishes with the top_db floor and the DCT itself (stage-mask bit 9 keeps dct_kernel)
-    const bool fuse = !(p->stage_mask & 512) && bdft_can_fuse_dct(p->n_frames, p->bd_seg, L);
+    // one workgroup per clip: on request (plan key 4) the kernel finishes with the top_db floor and the DCT itself
+    const bool fuse = p->bd_fuse_dct && bdft_can_fuse_dct(p->n_frames, p->bd_seg, L);
     BdftDct d;
     d.L = L; d.dct_frag = reinterpret_cast<const float4*>(p->d_dct); d.aff_mean = am; d.aff_scale = as; d.out = out;
     const int rc = launch_stft_bdft(a, p->bd, batch, p->bd_seg, fuse ? &d : nullptr, st);
@@ -2152,7 +2155,11 @@ static int plan_profile_end(MfccPlan* p, float* avg_ms3, int* n_calls) {
 
 static int plan_set(MfccPlan* p, int key, int value) {
   LP_CHECK_ARG(p != nullptr, "lipasr_mfcc_set: null plan");
-  LP_CHECK_ARG(key >= 0 && key <= 3, "lipasr_mfcc_set: unknown key %d", key);
+  LP_CHECK_ARG(key >= 0 && key <= 4, "lipasr_mfcc_set: unknown key %d", key);
+  if (key == 4) {
+    p->bd_fuse_dct = value != 0;
+    return LIPASR_OK;
+  }
   if (key == 3) {
     LP_CHECK_ARG(value >= 4 && value <= 4096 && (value & 3) == 0, "lipasr_mfcc_set: frames per workgroup %d (a multiple of 4)", value);
     p->bd_seg = value;

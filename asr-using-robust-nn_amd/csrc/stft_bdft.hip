@@ -200,6 +200,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       float b1024 = 0.0f;
 #pragma unroll
       for (int t2 = 0; t2 < 2; ++t2) {
+        // the tile's 8 twiddle quads leave for the registers before its first-stage matrix chain (they land behind it)
+        float4 tw8[8];
+#pragma unroll
+        for (int ep = 0; ep < 8; ++ep) tw8[ep] = twl[(t2 * 8 + ep) * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);
         // stage 1: tiles cos (re) and -sin (im) of k1 = 32 t2 + li; rows n2, K = n1
         bd_f32x16 a1[2];
 #pragma unroll
@@ -232,7 +237,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int ep = 4 * half + q;
-            const float4 t = twl[(t2 * 8 + ep) * 64 + lane];
+            const float4 t = tw8[ep];
             const float re0 = a1[0][2 * ep], im0 = a1[1][2 * ep], re1 = a1[0][2 * ep + 1], im1 = a1[1][2 * ep + 1];
             tr[2 * q] = re0 * t.x - im0 * t.y; tq[2 * q] = re0 * t.y + im0 * t.x;
             tr[2 * q + 1] = re1 * t.z - im1 * t.w; tq[2 * q + 1] = re1 * t.w + im1 * t.z;
@@ -273,26 +278,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int b = 0; b < 4; ++b) sb[b] = ring + ((fr + b) % kBdSlots) * kBdSlot;
       float xr[16], xi[16];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      // the four block spectra of bins 16 l + 4 q .. + 3, one quad ahead of the arithmetic (two sets of 8 float4 in flight:
+      // hoisting all four quads together would take 128 registers, none ahead exposes four LDS round trips)
+      float4 br[2][4], bi[2][4];
+      auto fetch_quad = [&](int q, float4 (&r)[4], float4 (&i)[4]) {
         const int k = 16 * lane + 4 * q;
         const int pos = k ^ (((k >> 6) & 7) << 2);
-        float4 br[4], bi[4];
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-          br[b] = *reinterpret_cast<const float4*>(sb[b] + pos);
-          bi[b] = *reinterpret_cast<const float4*>(sb[b] + kBdPlane + pos);
+          r[b] = *reinterpret_cast<const float4*>(sb[b] + pos);
+          i[b] = *reinterpret_cast<const float4*>(sb[b] + kBdPlane + pos);
         }
+      };
+      fetch_quad(0, br[0], bi[0]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (q < 3) fetch_quad(q + 1, br[(q + 1) & 1], bi[(q + 1) & 1]);
+        const float4 (&r)[4] = br[q & 1];
+        const float4 (&i)[4] = bi[q & 1];
         // X = B0 + w B1 + w^2 B2 + w^3 B3, w = (-i)^k, k mod 4 = the component
-        xr[4 * q + 0] = (br[0].x + br[2].x) + (br[1].x + br[3].x);
-        xi[4 * q + 0] = (bi[0].x + bi[2].x) + (bi[1].x + bi[3].x);
-        xr[4 * q + 1] = (br[0].y - br[2].y) + (bi[1].y - bi[3].y);
-        xi[4 * q + 1] = (bi[0].y - bi[2].y) - (br[1].y - br[3].y);
-        xr[4 * q + 2] = (br[0].z + br[2].z) - (br[1].z + br[3].z);
-        xi[4 * q + 2] = (bi[0].z + bi[2].z) - (bi[1].z + bi[3].z);
-        xr[4 * q + 3] = (br[0].w - br[2].w) - (bi[1].w - bi[3].w);
-        xi[4 * q + 3] = (bi[0].w - bi[2].w) + (br[1].w - br[3].w);
-        __builtin_amdgcn_sched_barrier(0);  // (keeps the 32 block reads from being hoisted together: 128 registers)
+        xr[4 * q + 0] = (r[0].x + r[2].x) + (r[1].x + r[3].x);
+        xi[4 * q + 0] = (i[0].x + i[2].x) + (i[1].x + i[3].x);
+        xr[4 * q + 1] = (r[0].y - r[2].y) + (i[1].y - i[3].y);
+        xi[4 * q + 1] = (i[0].y - i[2].y) - (r[1].y - r[3].y);
+        xr[4 * q + 2] = (r[0].z + r[2].z) - (r[1].z + r[3].z);
+        xi[4 * q + 2] = (i[0].z + i[2].z) - (i[1].z + i[3].z);
+        xr[4 * q + 3] = (r[0].w - r[2].w) - (i[1].w - i[3].w);
+        xi[4 * q + 3] = (i[0].w - i[2].w) + (r[1].w - r[3].w);
+        __builtin_amdgcn_sched_barrier(0);  // (pins the order: quad q + 1's reads are issued before quad q's arithmetic)
       }
       // neighbours across the lane boundary: X[16 l - 1] from the lane below (lane 0: X[-1] = conj X[1]), X[16 l + 16] from the
       // lane above (lane 63: X[1024] = sum of the four blocks' bin 1024, real)

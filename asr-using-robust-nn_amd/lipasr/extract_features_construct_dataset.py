@@ -55,7 +55,10 @@ class MfccExtractor:
     def set(self, key, value):
         """lipasr_mfcc_plan_set: key 0 = stage mask (64 = round-2 STFT kernel, 128 = never fuse), key 1 = resampler workgroups,
         key 2 = 1: the fused resample -> STFT kernel for every batch (default: only where the three kernels cannot read the
-        input: int16 / ragged rows that are not a multiple of 4 samples long)."""
+        input: int16 / ragged rows that are not a multiple of 4 samples long).  Stage-mask 256 = the Stockham STFT kernel
+        (stft_mel2_kernel, the parity reference of the block-DFT kernel); key 3 = frames per workgroup of the block-DFT kernel
+        (a multiple of 4, default 44); key 4 = 1: that kernel also applies the top_db floor and the DCT (no dct_kernel launch;
+        bit-identical, slower on cache-cold batches)."""
         N.check(N.lib.lipasr_mfcc_plan_set(self._plan, int(key), int(value)))
 
     def profile_begin(self, max_calls):

@@ -156,11 +156,9 @@ class TrainPipeline:
         # the three-kernel path's persistent resampler sizes its grid to one workgroup per CU it may use
         if hasattr(self.ex, "set"):
             self.ex.set(1, self.mfcc_cus)
-            if not self._custom_ex:
-                # On a CU share the STFT kernel's fused DCT epilogue (one workgroup per clip holds its 74 kB of LDS while two
-                # of its four wavefronts run the fp32 DCT) loses to the separate dct_kernel: stage 0.400 against 0.388 ms on
-                # 96 CUs, step 0.434 against 0.418 ms (round 4); alone on the whole chip it wins (0.124 against 0.138 ms)
-                self.ex.set(0, 512)
+            # (the STFT kernel's fused DCT epilogue, plan key 4, stays off: on a CU share one workgroup per clip holding its 74 kB of
+            # LDS while two of its four wavefronts run the fp32 DCT loses to the separate dct_kernel -- stage 0.400 against 0.388 ms
+            # on 96 CUs, step 0.434 against 0.418 ms, round 4)
         # the classifier's stream on the CUs the MFCC stream does not use
         want = self._train_cus if self._train_cus != "auto" else os.environ.get("LIPASR_TRAIN_CUS", "all" if (self._custom_ex or self.pgd) else "rest")
         if want == "rest" and k < n_groups:

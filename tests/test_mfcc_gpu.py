@@ -406,8 +406,8 @@ def test_block_dft_kernel_against_stockham_kernel_and_oracle(cuda):
 
 @pytest.mark.parametrize("L", [44, 30, 50, 64])
 def test_fused_dct_epilogue_is_bit_identical_to_dct_kernel(cuda, L):
-    """One workgroup per clip: stft_bdft_kernel ends with the top_db floor and the DCT itself (no dct_kernel launch, the dB
-    tile never leaves L2).  Same instructions in the same order as dct_kernel => the same bits, with and without the fused
+    """One workgroup per clip, on request (plan key 4): stft_bdft_kernel ends with the top_db floor and the DCT itself (no
+    dct_kernel launch, the dB tile comes back from L2).  Same instructions in the same order as dct_kernel => the same bits, with and without the fused
     StandardScaler affine, for utterance lengths shorter and longer than the clip's 44 frames; ragged batches too."""
     from lipasr.extract_features_construct_dataset import MfccExtractor
     from lipasr.synth import synth_clips
@@ -419,9 +419,9 @@ def test_fused_dct_epilogue_is_bit_identical_to_dct_kernel(cuda, L):
     scale = torch.linspace(0.5, 2, 20 * L, device="cuda", dtype=torch.float64)
     nv = torch.as_tensor(np.random.default_rng(L).integers(1000, 16001, 37).astype(np.int32) // 4 * 4).cuda()
     outs = {}
-    for mask in (0, 512):  # 512: keep dct_kernel
-        ex.set(0, mask)
-        outs[mask] = (ex(wt, L).clone(), ex(wt, L, mean, scale).clone(), ex(wt, L, n_valid=nv).clone())
-    ex.set(0, 0)
-    for a, b in zip(outs[0], outs[512]):
+    for fuse in (0, 1):  # plan key 4: the STFT kernel's own DCT epilogue
+        ex.set(4, fuse)
+        outs[fuse] = (ex(wt, L).clone(), ex(wt, L, mean, scale).clone(), ex(wt, L, n_valid=nv).clone())
+    ex.set(4, 0)
+    for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a, b)
