@@ -133,6 +133,286 @@ __device__ __forceinline__ void bd_fetch(const float* __restrict__ yu, int jg, i
   }
 }
 
+struct BdConst {
+  bd_h8 ch[4], cl[4], eh[4], el[4];  // constant operands of the two matrix stages: 64 registers
+};
+
+__device__ __forceinline__ void bd_load_const(const BdftArgs& a, int lane, BdConst& K) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    K.ch[t] = __builtin_bit_cast(bd_h8, a.cfrag[(2 * t + 0) * 64 + lane]);
+    K.cl[t] = __builtin_bit_cast(bd_h8, a.cfrag[(2 * t + 1) * 64 + lane]);
+    K.eh[t] = __builtin_bit_cast(bd_h8, a.efrag[(2 * t + 0) * 64 + lane]);
+    K.el[t] = __builtin_bit_cast(bd_h8, a.efrag[(2 * t + 1) * 64 + lane]);
+  }
+}
+
+// the staging positions summed into mel `lane` and mel `lane + 64`: 12 positions, two per register
+__device__ __forceinline__ void bd_load_mpos(const BdftArgs& a, int lane, unsigned (&mp)[6]) {
+  const int4 pa0 = a.mpos[2 * lane], pb0 = a.mpos[2 * lane + 1], pa1 = a.mpos[2 * (lane + 64)], pb1 = a.mpos[2 * (lane + 64) + 1];
+  mp[0] = (unsigned)pa0.x | ((unsigned)pa0.y << 16); mp[1] = (unsigned)pa0.z | ((unsigned)pb0.x << 16); mp[2] = (unsigned)pb0.y | ((unsigned)pb0.z << 16);
+  mp[3] = (unsigned)pa1.x | ((unsigned)pa1.y << 16); mp[4] = (unsigned)pa1.z | ((unsigned)pb1.x << 16); mp[5] = (unsigned)pb1.y | ((unsigned)pb1.z << 16);
+}
+
+// the lane's 8 samples -> the two fp16 planes of the first stage's data operand
+__device__ __forceinline__ void bd_data_planes(const float (&ys)[8], bd_h8& ah, bd_h8& al) {
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = fminf(fmaxf(ys[i] * (float)kBdSig, -65000.0f), 65000.0f);
+  bd_split8(v, ah, al);
+}
+
+// One block of 512 samples (data planes ah / al) -> its spectrum, bins 0 .. 1024, into the ring slot `slot_base`
+__device__ __forceinline__ void bd_block(const bd_h8& ah, const bd_h8& al, const BdConst& K, const float4* __restrict__ twl,
+                                         float* __restrict__ slot_base, int lane) {
+  const int li = lane & 31, h = lane >> 5, k2 = li & 15, plane = li >> 4;
+  float* slot = slot_base + plane * kBdPlane;
+  float b1024 = 0.0f;
+#pragma unroll
+  for (int t2 = 0; t2 < 2; ++t2) {
+    // the tile's 8 twiddle quads leave for the registers before its first-stage matrix chain (they land behind it)
+    float4 tw8[8];
+#pragma unroll
+    for (int ep = 0; ep < 8; ++ep) tw8[ep] = twl[(t2 * 8 + ep) * 64 + lane];
+    __builtin_amdgcn_sched_barrier(0);
+    // stage 1: tiles cos (re) and -sin (im) of k1 = 32 t2 + li; rows n2, K = n1
+    bd_f32x16 a1[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int t = 2 * c + t2;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) a1[c][e] = 0.0f;
+      a1[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, K.ch[t], a1[c], 0, 0, 0);
+      a1[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, K.cl[t], a1[c], 0, 0, 0);
+      a1[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, K.ch[t], a1[c], 0, 0, 0);
+    }
+    if (t2 == 0) {
+      // bin 1024 (k1 = 0 with k2 = 16: outside the second stage's 16 columns) = sum_m y[m] (-1)^m = sum_n2 (-1)^n2 A[n2][0]:
+      // column 0 of the first cosine tile, i.e. lanes 0 and 32, register parity = n2 parity
+      float s8 = 0.0f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s8 += (e & 1) ? -a1[0][e] : a1[0][e];
+      b1024 = (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(s8), 0)) +
+               __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s8), 32))) * (float)(kBdMid * kBdTap);
+    }
+    // inter-stage twiddle, split into planes, second stage.  Register e of this lane is n2 = (e & 3) + 8 (e >> 2) + 4 h,
+    // k1 = 32 t2 + li; the second stage contracts over (re | im) x n2 in accumulator order: k-step s = 2 c + half takes
+    // component c of registers 8 half .. 8 half + 7; columns (16 re | 16 im) of k2
+    bd_f32x16 a3;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) a3[e] = 0.0f;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      float tr[8], tq[8];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int ep = 4 * half + q;
+        const float4 t = tw8[ep];
+        const float re0 = a1[0][2 * ep], im0 = a1[1][2 * ep], re1 = a1[0][2 * ep + 1], im1 = a1[1][2 * ep + 1];
+        tr[2 * q] = re0 * t.x - im0 * t.y; tq[2 * q] = re0 * t.y + im0 * t.x;
+        tr[2 * q + 1] = re1 * t.z - im1 * t.w; tq[2 * q + 1] = re1 * t.w + im1 * t.z;
+      }
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int s = 2 * c + half;
+        bd_h8 oh, ol;
+        bd_split8(c ? tq : tr, oh, ol);
+        a3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(oh, K.eh[s], a3, 0, 0, 0);
+        a3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(oh, K.el[s], a3, 0, 0, 0);
+        a3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ol, K.eh[s], a3, 0, 0, 0);
+      }
+    }
+    // lane (column li = (plane, k2), h): registers 4 b .. 4 b + 3 are bins k = 64 k2 + 32 t2 + 8 b + 4 h + (0 .. 3)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int k = 64 * k2 + 32 * t2 + 8 * b + 4 * h;
+      *reinterpret_cast<float4*>(slot + (k ^ ((k2 & 7) << 2))) = make_float4(a3[4 * b], a3[4 * b + 1], a3[4 * b + 2], a3[4 * b + 3]);
+    }
+  }
+  if (lane == 0) slot[1024] = b1024;
+  if (lane == 16) slot[1024] = 0.0f;  // (plane 1)
+}
+
+// One frame: its four block spectra sb[0 .. 3] -> combine -> Hann taps -> power -> segmented scans of the two mel weight planes
+// (wl / wh: the lane's 16 + 16 mel weights)
+__device__ __forceinline__ void bd_frame_scan(const float* const (&sb)[4], const float (&wl)[16], const float (&wh)[16],
+                                              const unsigned long long (&sm)[16], int lane, float (&sl)[16], float (&sh)[16]) {
+  float xr[16], xi[16];
+  // the four block spectra of bins 16 l + 4 q .. + 3, one quad ahead of the arithmetic (two sets of 8 float4 in flight:
+  // hoisting all four quads together would take 128 registers, none ahead exposes four LDS round trips)
+  float4 br[2][4], bi[2][4];
+  auto fetch_quad = [&](int q, float4 (&r)[4], float4 (&i)[4]) {
+    const int k = 16 * lane + 4 * q;
+    const int pos = k ^ (((k >> 6) & 7) << 2);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      r[b] = *reinterpret_cast<const float4*>(sb[b] + pos);
+      i[b] = *reinterpret_cast<const float4*>(sb[b] + kBdPlane + pos);
+    }
+  };
+  fetch_quad(0, br[0], bi[0]);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (q < 3) fetch_quad(q + 1, br[(q + 1) & 1], bi[(q + 1) & 1]);
+    const float4 (&r)[4] = br[q & 1];
+    const float4 (&i)[4] = bi[q & 1];
+    // X = B0 + w B1 + w^2 B2 + w^3 B3, w = (-i)^k, k mod 4 = the component
+    xr[4 * q + 0] = (r[0].x + r[2].x) + (r[1].x + r[3].x);
+    xi[4 * q + 0] = (i[0].x + i[2].x) + (i[1].x + i[3].x);
+    xr[4 * q + 1] = (r[0].y - r[2].y) + (i[1].y - i[3].y);
+    xi[4 * q + 1] = (i[0].y - i[2].y) - (r[1].y - r[3].y);
+    xr[4 * q + 2] = (r[0].z + r[2].z) - (r[1].z + r[3].z);
+    xi[4 * q + 2] = (i[0].z + i[2].z) - (i[1].z + i[3].z);
+    xr[4 * q + 3] = (r[0].w - r[2].w) - (i[1].w - i[3].w);
+    xi[4 * q + 3] = (i[0].w - i[2].w) + (r[1].w - r[3].w);
+    __builtin_amdgcn_sched_barrier(0);  // (pins the order: quad q + 1's reads are issued before quad q's arithmetic)
+  }
+  // neighbours across the lane boundary: X[16 l - 1] from the lane below (lane 0: X[-1] = conj X[1]), X[16 l + 16] from the
+  // lane above (lane 63: X[1024] = sum of the four blocks' bin 1024, real)
+  float lr = bd_from_below(xr[15]), lq = bd_from_below(xi[15]);
+  float ur = bd_from_above(xr[0]), uq = bd_from_above(xi[0]);
+  const float x1024 = (sb[0][1024] + sb[2][1024]) + (sb[1][1024] + sb[3][1024]);
+  if (lane == 0) { lr = xr[1]; lq = -xi[1]; }
+  if (lane == 63) { ur = x1024; uq = 0.0f; }
+  float pw[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const float mr = (j ? xr[j - 1] : lr) + (j < 15 ? xr[j + 1] : ur);
+    const float mq = (j ? xi[j - 1] : lq) + (j < 15 ? xi[j + 1] : uq);
+    const float hr = xr[j] - 0.5f * mr, hq = xi[j] - 0.5f * mq;  // 2 Xw (the 1/4 of the power is in the weights)
+    pw[j] = hr * hr + hq * hq;
+  }
+  // segmented scan of the weighted powers over the lane's 16 bins: a sum restarts where a mel run opens
+  float cl_ = 0.0f, ch_ = 0.0f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    float pl_, ph_;
+    if (j == 0) {
+      pl_ = 0.0f; ph_ = 0.0f;
+    } else {
+      asm("v_cndmask_b32 %0, %1, 0, %2" : "=v"(pl_) : "v"(cl_), "s"(sm[j]));
+      asm("v_cndmask_b32 %0, %1, 0, %2" : "=v"(ph_) : "v"(ch_), "s"(sm[j]));
+    }
+    cl_ = fmaf(wl[j], pw[j], pl_);
+    ch_ = fmaf(wh[j], pw[j], ph_);
+    sl[j] = cl_; sh[j] = ch_;
+  }
+}
+
+__device__ __forceinline__ void bd_load_weights(const BdftArgs& a, int lane, float (&wl)[16], float (&wh)[16]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 l4 = reinterpret_cast<const float4*>(a.wlo)[4 * lane + q], h4 = reinterpret_cast<const float4*>(a.whi)[4 * lane + q];
+    wl[4 * q] = l4.x; wl[4 * q + 1] = l4.y; wl[4 * q + 2] = l4.z; wl[4 * q + 3] = l4.w;
+    wh[4 * q] = h4.x; wh[4 * q + 1] = h4.y; wh[4 * q + 2] = h4.z; wh[4 * q + 3] = h4.w;
+  }
+}
+
+// scans -> staging `stg` (2056 floats no other wavefront touches now) -> mel `lane` and `lane + 64` -> dB -> a.st.db; returns the
+// frame's maximum (wave-uniform; lane 0 also stores it to a.st.fmax)
+__device__ __forceinline__ float bd_frame_finish(const BdftArgs& a, float* __restrict__ stg, const float (&sl)[16], const float (&sh)[16],
+                                                 const unsigned (&mp)[6], int lane, int u, int f) {
+  const int x = (lane >> 2) & 3;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    *reinterpret_cast<float4*>(stg + 16 * lane + 4 * (q ^ x)) = make_float4(sl[4 * q], sl[4 * q + 1], sl[4 * q + 2], sl[4 * q + 3]);
+    *reinterpret_cast<float4*>(stg + 1024 + 16 * lane + 4 * (q ^ x)) = make_float4(sh[4 * q], sh[4 * q + 1], sh[4 * q + 2], sh[4 * q + 3]);
+  }
+  if (lane == 0) stg[kBdDummy] = 0.0f;
+  const float m0 = ((stg[mp[0] & 0xffff] + stg[mp[0] >> 16]) + stg[mp[1] & 0xffff]) + ((stg[mp[1] >> 16] + stg[mp[2] & 0xffff]) + stg[mp[2] >> 16]);
+  const float m1 = ((stg[mp[3] & 0xffff] + stg[mp[3] >> 16]) + stg[mp[4] & 0xffff]) + ((stg[mp[4] >> 16] + stg[mp[5] & 0xffff]) + stg[mp[5] >> 16]);
+  const float d0 = 10.0f * log10f(fmaxf(1e-10f, m0)), d1 = 10.0f * log10f(fmaxf(1e-10f, m1));
+  float* dbp = a.st.db + ((size_t)u * a.st.n_frames + f) * 128;
+  dbp[lane] = d0;
+  dbp[lane + 64] = d1;
+  const float mx = bd_wave_max(fmaxf(d0, d1));
+  if (lane == 0) a.st.fmax[(size_t)u * a.st.n_frames + f] = mx;
+  return mx;
+}
+
+// The optional fused epilogue: dct_kernel's arithmetic, instruction for instruction (mfcc.hip), on this workgroup's own dB tile:
+// top_db floor against the clip maximum, DCT-II as a 32 x 32 x 128 contraction per wavefront on v_mfma_f32_32x32x2_f32
+// (wavefronts 0 and 1: 32 frames each), optional affine in fp64.  The tile comes back from L2 (this workgroup stored it); the
+// ring is free by now and holds the transposed image.  NT = threads of the workgroup; red: one float per wavefront.
+template <int NT>
+__device__ __forceinline__ void bd_dct_epilogue(const BdftArgs& a, float* __restrict__ dbs, float* __restrict__ red, int tid, int u, int nf, float clip_max) {
+  const int lane = tid & 63, wave = tid >> 6, li = lane & 31, h = lane >> 5;
+  const int L = a.L;
+  const int chunk = min(64, (L + 3) & ~3), tp = chunk + 1;
+  const int tl = min(chunk, L), tu = max(0, min(nf, tl));
+  __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wavefront's dB stores have left
+  lds_barrier2();                      // every wavefront is done with ring and staging
+  if (lane == 0) red[wave] = clip_max;
+  __syncthreads();
+  float mxall = red[0];
+#pragma unroll
+  for (int w = 1; w < NT / 64; ++w) mxall = fmaxf(mxall, red[w]);
+  const float thr = mxall - 80.0f;  // top_db = 80
+  const float* src = a.st.db + (size_t)u * a.st.n_frames * 128;
+  const int n_live = tu * 128;
+  constexpr int NJ = 64 * 128 / NT;
+  float stage[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int i = tid + NT * j;  // frame i / 128, mel i % 128
+    stage[j] = (i < n_live) ? __builtin_nontemporal_load(src + i) : 0.0f;
+  }
+  float4 av4[16];
+  const float4* ap = a.dct_frag + (li * 2 + h) * 16;
+  if (wave < 2) {
+#pragma unroll
+    for (int s4 = 0; s4 < 16; ++s4) av4[s4] = ap[s4];
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int i = tid + NT * j, t = i >> 7;
+    if (t < chunk) dbs[(i & 127) * tp + t] = (i < n_live) ? fmaxf(stage[j], thr) : 0.0f;
+  }
+  __syncthreads();
+  if (wave < 2) {
+    bd_f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+    const float* bp = dbs + h * tp + min(wave * 32 + li, chunk - 1);
+#pragma unroll
+    for (int s4 = 0; s4 < 16; ++s4) {
+      const float a4[4] = {av4[s4].x, av4[s4].y, av4[s4].z, av4[s4].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], bp[2 * (4 * s4 + e) * tp], acc, 0, 0, 0);
+    }
+    const int t = wave * 32 + li;
+    const int n_out = kNMfcc * L;
+    if (t < tl) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int c = (q & 3) + 8 * (q >> 2) + 4 * h;
+        if (c < kNMfcc) {
+          float v = (t < tu) ? acc[q] : 0.0f;
+          const int oo = c * L + t;
+          if (a.aff_mean) v = (float)(((double)v - a.aff_mean[oo]) / a.aff_scale[oo]);
+          a.out[(size_t)u * n_out + oo] = v;
+        }
+      }
+    }
+  }
+}
+
+// this clip's own lengths (per-clip lengths: frame count and reflect padding follow them)
+__device__ __forceinline__ void bd_clip(const BdftArgs& a, int u, int& n_y, int& n_vy, int& n_frames) {
+  n_y = a.st.n_y; n_frames = a.st.n_frames; n_vy = a.st.n_y;
+  if (a.st.n_valid) {
+    clip_lengths(min(max(a.st.n_valid[u], 0), a.st.n_samp_max), a.st.sr_in, &n_vy, &n_y, &n_frames);
+    n_frames = min(n_frames, a.st.n_frames);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The kernel: four wavefronts, two workgroups per CU; every wavefront alternates between one block and one frame; ring of 7
+// block spectra; the staging slot of a wavefront is the ring slot it overwrites next.  Two LDS-only barriers per iteration.
+// (Measured and not kept, round 4: a split-role form -- eight wavefronts, four that only transform blocks and four that only
+// finish frames one iteration behind, ring of 11, one barrier per iteration -- 130 us against 121: its phases alone cost
+// 27 us skeleton + 77 us blocks + 52 us frames and overlap only halfway)
+// ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void stft_bdft_kernel(BdftArgs a) {
   extern __shared__ __attribute__((aligned(16))) float bd_lds[];
   float* ring = bd_lds;
@@ -141,25 +421,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, h = lane >> 5;
   const int u = blockIdx.y;
-  int n_y = a.st.n_y, n_frames = a.st.n_frames, n_vy = a.st.n_y;
-  if (a.st.n_valid) {  // this clip's own length: frame count and reflect padding follow it
-    clip_lengths(min(max(a.st.n_valid[u], 0), a.st.n_samp_max), a.st.sr_in, &n_vy, &n_y, &n_frames);
-    n_frames = min(n_frames, a.st.n_frames);
-  }
+  int n_y, n_vy, n_frames;
+  bd_clip(a, u, n_y, n_vy, n_frames);
   const int F0 = blockIdx.x * a.seg_frames;
   // (workgroup-uniform, before any barrier.  With the fused epilogue a clip without a frame still gets its zero columns,
   // fix_frames' padding, extract_features_construct_dataset.py:33-37)
   if (F0 >= n_frames && a.L <= 0) return;
   const int F1 = min(F0 + a.seg_frames, n_frames);
-  // constant operands of the two matrix stages: 64 registers for the whole kernel
-  bd_h8 ch[4], cl[4], eh[4], el[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    ch[t] = __builtin_bit_cast(bd_h8, a.cfrag[(2 * t + 0) * 64 + lane]);
-    cl[t] = __builtin_bit_cast(bd_h8, a.cfrag[(2 * t + 1) * 64 + lane]);
-    eh[t] = __builtin_bit_cast(bd_h8, a.efrag[(2 * t + 0) * 64 + lane]);
-    el[t] = __builtin_bit_cast(bd_h8, a.efrag[(2 * t + 1) * 64 + lane]);
-  }
+  BdConst K;
+  bd_load_const(a, lane, K);
   unsigned long long sm[16];
 #pragma unroll
   for (int j = 0; j < 16; ++j) sm[j] = a.smask[j];
@@ -168,14 +438,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   __syncthreads();
   const float* yu = a.st.y + (size_t)u * a.st.n_y;
   const int n_iter = (F0 < n_frames) ? (F1 - F0 + 3) >> 2 : -1;  // -1: no frame, the loop below does not run
-  const int k2 = li & 15, plane = li >> 4;
-  // segment ends summed into mel `lane` and mel `lane + 64`: 12 staging positions, two per register
   unsigned mp[6];
-  {
-    const int4 pa0 = a.mpos[2 * lane], pb0 = a.mpos[2 * lane + 1], pa1 = a.mpos[2 * (lane + 64)], pb1 = a.mpos[2 * (lane + 64) + 1];
-    mp[0] = (unsigned)pa0.x | ((unsigned)pa0.y << 16); mp[1] = (unsigned)pa0.z | ((unsigned)pb0.x << 16); mp[2] = (unsigned)pb0.y | ((unsigned)pb0.z << 16);
-    mp[3] = (unsigned)pa1.x | ((unsigned)pa1.y << 16); mp[4] = (unsigned)pa1.z | ((unsigned)pb1.x << 16); mp[5] = (unsigned)pb1.y | ((unsigned)pb1.z << 16);
-  }
+  bd_load_mpos(a, lane, mp);
   float clip_max = -INFINITY;  // over this wavefront's frames (fused epilogue)
   float ys[8];
 #pragma unroll
@@ -187,246 +451,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int jg = F0 + rel;
     const bool do_block = rel >= 0 && jg <= F1 + 2;  // (wave-uniform)
     bd_h8 ah, al;
-    if (do_block) {
-      float v[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = fminf(fmaxf(ys[i] * (float)kBdSig, -65000.0f), 65000.0f);
-      bd_split8(v, ah, al);
-    }
+    if (do_block) bd_data_planes(ys, ah, al);
     // the NEXT block's samples leave now: an HBM round trip that has a whole iteration to come back
     if (jg + 4 <= F1 + 2) bd_fetch(yu, jg + 4, li, h, n_y, n_vy, ys);
-    if (do_block) {
-      float* slot = ring + (rel % kBdSlots) * kBdSlot + plane * kBdPlane;
-      float b1024 = 0.0f;
-#pragma unroll
-      for (int t2 = 0; t2 < 2; ++t2) {
-        // the tile's 8 twiddle quads leave for the registers before its first-stage matrix chain (they land behind it)
-        float4 tw8[8];
-#pragma unroll
-        for (int ep = 0; ep < 8; ++ep) tw8[ep] = twl[(t2 * 8 + ep) * 64 + lane];
-        __builtin_amdgcn_sched_barrier(0);
-        // stage 1: tiles cos (re) and -sin (im) of k1 = 32 t2 + li; rows n2, K = n1
-        bd_f32x16 a1[2];
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const int t = 2 * c + t2;
-#pragma unroll
-          for (int e = 0; e < 16; ++e) a1[c][e] = 0.0f;
-          a1[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ch[t], a1[c], 0, 0, 0);
-          a1[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, cl[t], a1[c], 0, 0, 0);
-          a1[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, ch[t], a1[c], 0, 0, 0);
-        }
-        if (t2 == 0) {
-          // bin 1024 (k1 = 0 with k2 = 16: outside the second stage's 16 columns) = sum_m y[m] (-1)^m = sum_n2 (-1)^n2 A[n2][0]:
-          // column 0 of the first cosine tile, i.e. lanes 0 and 32, register parity = n2 parity
-          float s8 = 0.0f;
-#pragma unroll
-          for (int e = 0; e < 16; ++e) s8 += (e & 1) ? -a1[0][e] : a1[0][e];
-          b1024 = (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(s8), 0)) +
-                   __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s8), 32))) * (float)(kBdMid * kBdTap);
-        }
-        // inter-stage twiddle, split into planes, second stage.  Register e of this lane is n2 = (e & 3) + 8 (e >> 2) + 4 h,
-        // k1 = 32 t2 + li; the second stage contracts over (re | im) x n2 in accumulator order: k-step s = 2 c + half takes
-        // component c of registers 8 half .. 8 half + 7; columns (16 re | 16 im) of k2
-        bd_f32x16 a3;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) a3[e] = 0.0f;
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          float tr[8], tq[8];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int ep = 4 * half + q;
-            const float4 t = tw8[ep];
-            const float re0 = a1[0][2 * ep], im0 = a1[1][2 * ep], re1 = a1[0][2 * ep + 1], im1 = a1[1][2 * ep + 1];
-            tr[2 * q] = re0 * t.x - im0 * t.y; tq[2 * q] = re0 * t.y + im0 * t.x;
-            tr[2 * q + 1] = re1 * t.z - im1 * t.w; tq[2 * q + 1] = re1 * t.w + im1 * t.z;
-          }
-#pragma unroll
-          for (int c = 0; c < 2; ++c) {
-            const int s = 2 * c + half;
-            bd_h8 oh, ol;
-            bd_split8(c ? tq : tr, oh, ol);
-            a3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(oh, eh[s], a3, 0, 0, 0);
-            a3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(oh, el[s], a3, 0, 0, 0);
-            a3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ol, eh[s], a3, 0, 0, 0);
-          }
-        }
-        // lane (column li = (plane, k2), h): registers 4 b .. 4 b + 3 are bins k = 64 k2 + 32 t2 + 8 b + 4 h + (0 .. 3)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          const int k = 64 * k2 + 32 * t2 + 8 * b + 4 * h;
-          *reinterpret_cast<float4*>(slot + (k ^ ((k2 & 7) << 2))) = make_float4(a3[4 * b], a3[4 * b + 1], a3[4 * b + 2], a3[4 * b + 3]);
-        }
-      }
-      if (lane == 0) slot[1024] = b1024;
-      if (lane == 16) slot[1024] = 0.0f;  // (plane 1)
-    }
+    if (do_block) bd_block(ah, al, K, twl, ring + (rel % kBdSlots) * kBdSlot, lane);
     // ---------------------------------------------------------------- one frame per wavefront
     const int fr = 4 * it + wave, f = F0 + fr;
     const bool do_frame = it >= 0 && f < F1;
     lds_barrier2();
     float sl[16], sh[16];
     if (do_frame) {
-      float4 wl4[4], wh4[4];  // the lane's 32 mel weights (L1 / L2 resident), wanted after the combine
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        wl4[q] = reinterpret_cast<const float4*>(a.wlo)[4 * lane + q];
-        wh4[q] = reinterpret_cast<const float4*>(a.whi)[4 * lane + q];
-      }
+      float wl[16], wh[16];  // the lane's 32 mel weights (L1 / L2 resident), wanted after the combine
+      bd_load_weights(a, lane, wl, wh);
       const float* sb[4];
 #pragma unroll
       for (int b = 0; b < 4; ++b) sb[b] = ring + ((fr + b) % kBdSlots) * kBdSlot;
-      float xr[16], xi[16];
-      // the four block spectra of bins 16 l + 4 q .. + 3, one quad ahead of the arithmetic (two sets of 8 float4 in flight:
-      // hoisting all four quads together would take 128 registers, none ahead exposes four LDS round trips)
-      float4 br[2][4], bi[2][4];
-      auto fetch_quad = [&](int q, float4 (&r)[4], float4 (&i)[4]) {
-        const int k = 16 * lane + 4 * q;
-        const int pos = k ^ (((k >> 6) & 7) << 2);
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          r[b] = *reinterpret_cast<const float4*>(sb[b] + pos);
-          i[b] = *reinterpret_cast<const float4*>(sb[b] + kBdPlane + pos);
-        }
-      };
-      fetch_quad(0, br[0], bi[0]);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (q < 3) fetch_quad(q + 1, br[(q + 1) & 1], bi[(q + 1) & 1]);
-        const float4 (&r)[4] = br[q & 1];
-        const float4 (&i)[4] = bi[q & 1];
-        // X = B0 + w B1 + w^2 B2 + w^3 B3, w = (-i)^k, k mod 4 = the component
-        xr[4 * q + 0] = (r[0].x + r[2].x) + (r[1].x + r[3].x);
-        xi[4 * q + 0] = (i[0].x + i[2].x) + (i[1].x + i[3].x);
-        xr[4 * q + 1] = (r[0].y - r[2].y) + (i[1].y - i[3].y);
-        xi[4 * q + 1] = (i[0].y - i[2].y) - (r[1].y - r[3].y);
-        xr[4 * q + 2] = (r[0].z + r[2].z) - (r[1].z + r[3].z);
-        xi[4 * q + 2] = (i[0].z + i[2].z) - (i[1].z + i[3].z);
-        xr[4 * q + 3] = (r[0].w - r[2].w) - (i[1].w - i[3].w);
-        xi[4 * q + 3] = (i[0].w - i[2].w) + (r[1].w - r[3].w);
-        __builtin_amdgcn_sched_barrier(0);  // (pins the order: quad q + 1's reads are issued before quad q's arithmetic)
-      }
-      // neighbours across the lane boundary: X[16 l - 1] from the lane below (lane 0: X[-1] = conj X[1]), X[16 l + 16] from the
-      // lane above (lane 63: X[1024] = sum of the four blocks' bin 1024, real)
-      float lr = bd_from_below(xr[15]), lq = bd_from_below(xi[15]);
-      float ur = bd_from_above(xr[0]), uq = bd_from_above(xi[0]);
-      const float x1024 = (sb[0][1024] + sb[2][1024]) + (sb[1][1024] + sb[3][1024]);
-      if (lane == 0) { lr = xr[1]; lq = -xi[1]; }
-      if (lane == 63) { ur = x1024; uq = 0.0f; }
-      float pw[16];
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const float mr = (j ? xr[j - 1] : lr) + (j < 15 ? xr[j + 1] : ur);
-        const float mq = (j ? xi[j - 1] : lq) + (j < 15 ? xi[j + 1] : uq);
-        const float hr = xr[j] - 0.5f * mr, hq = xi[j] - 0.5f * mq;  // 2 Xw (the 1/4 of the power is in the weights)
-        pw[j] = hr * hr + hq * hq;
-      }
-      // segmented scan of the weighted powers over the lane's 16 bins: a sum restarts where a mel run opens
-      const float wl[16] = {wl4[0].x, wl4[0].y, wl4[0].z, wl4[0].w, wl4[1].x, wl4[1].y, wl4[1].z, wl4[1].w,
-                            wl4[2].x, wl4[2].y, wl4[2].z, wl4[2].w, wl4[3].x, wl4[3].y, wl4[3].z, wl4[3].w};
-      const float wh[16] = {wh4[0].x, wh4[0].y, wh4[0].z, wh4[0].w, wh4[1].x, wh4[1].y, wh4[1].z, wh4[1].w,
-                            wh4[2].x, wh4[2].y, wh4[2].z, wh4[2].w, wh4[3].x, wh4[3].y, wh4[3].z, wh4[3].w};
-      float cl_ = 0.0f, ch_ = 0.0f;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        float pl_, ph_;
-        if (j == 0) {
-          pl_ = 0.0f; ph_ = 0.0f;
-        } else {
-          asm("v_cndmask_b32 %0, %1, 0, %2" : "=v"(pl_) : "v"(cl_), "s"(sm[j]));
-          asm("v_cndmask_b32 %0, %1, 0, %2" : "=v"(ph_) : "v"(ch_), "s"(sm[j]));
-        }
-        cl_ = fmaf(wl[j], pw[j], pl_);
-        ch_ = fmaf(wh[j], pw[j], ph_);
-        sl[j] = cl_; sh[j] = ch_;
-      }
+      bd_frame_scan(sb, wl, wh, sm, lane, sl, sh);
     }
     lds_barrier2();  // every wavefront has read its four block spectra: blocks fr' .. fr' + 3 of this iteration are free
     if (do_frame) {
       // staging = the slot of block 4 it + wave, which is also the slot this wavefront's next block goes to
-      float* stg = ring + (fr % kBdSlots) * kBdSlot;
-      const int x = (lane >> 2) & 3;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        *reinterpret_cast<float4*>(stg + 16 * lane + 4 * (q ^ x)) = make_float4(sl[4 * q], sl[4 * q + 1], sl[4 * q + 2], sl[4 * q + 3]);
-        *reinterpret_cast<float4*>(stg + 1024 + 16 * lane + 4 * (q ^ x)) = make_float4(sh[4 * q], sh[4 * q + 1], sh[4 * q + 2], sh[4 * q + 3]);
-      }
-      if (lane == 0) stg[kBdDummy] = 0.0f;
-      const float m0 = ((stg[mp[0] & 0xffff] + stg[mp[0] >> 16]) + stg[mp[1] & 0xffff]) + ((stg[mp[1] >> 16] + stg[mp[2] & 0xffff]) + stg[mp[2] >> 16]);
-      const float m1 = ((stg[mp[3] & 0xffff] + stg[mp[3] >> 16]) + stg[mp[4] & 0xffff]) + ((stg[mp[4] >> 16] + stg[mp[5] & 0xffff]) + stg[mp[5] >> 16]);
-      const float d0 = 10.0f * log10f(fmaxf(1e-10f, m0)), d1 = 10.0f * log10f(fmaxf(1e-10f, m1));
-      float* dbp = a.st.db + ((size_t)u * a.st.n_frames + f) * 128;
-      dbp[lane] = d0;
-      dbp[lane + 64] = d1;
-      const float mx = bd_wave_max(fmaxf(d0, d1));
-      if (lane == 0) a.st.fmax[(size_t)u * a.st.n_frames + f] = mx;
+      const float mx = bd_frame_finish(a, ring + (fr % kBdSlots) * kBdSlot, sl, sh, mp, lane, u, f);
       clip_max = fmaxf(clip_max, mx);
     }
   }
   if (a.L <= 0) return;
-  // ---------------------------------------------------------------- fused epilogue: dct_kernel's arithmetic, instruction for
-  // instruction (mfcc.hip), on this workgroup's own dB tile: top_db floor against the clip maximum, DCT-II as a 32 x 32 x 128
-  // contraction per wavefront on v_mfma_f32_32x32x2_f32 (wavefronts 0 and 1: 32 frames each), optional affine in fp64.  The
-  // tile comes back from L2 (this workgroup stored it); the ring is free now and holds the transposed image.
-  {
-    float* dbs = ring;                       // [128][tp] = [m][t]
-    float* red = ring + 128 * 65;            // 4 floats behind the largest image
-    const int L = a.L, nf = n_frames;
-    const int chunk = min(64, (L + 3) & ~3), tp = chunk + 1;
-    const int tl = min(chunk, L), tu = max(0, min(nf, tl));
-    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wavefront's dB stores have left
-    lds_barrier2();                      // every wavefront is done with its staging slot: the ring is free
-    if (lane == 0) red[wave] = clip_max;
-    __syncthreads();
-    const float thr = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) - 80.0f;  // top_db = 80
-    const float* src = a.st.db + (size_t)u * a.st.n_frames * 128;
-    const int n_live = tu * 128;
-    float stage[32];
-#pragma unroll
-    for (int j = 0; j < 32; ++j) {
-      const int i = tid + 256 * j;  // frame 2 j + (tid >> 7), mel tid & 127
-      stage[j] = (i < n_live) ? __builtin_nontemporal_load(src + i) : 0.0f;
-    }
-    float4 av4[16];
-    const float4* ap = a.dct_frag + (li * 2 + h) * 16;
-    if (wave < 2) {
-#pragma unroll
-      for (int s4 = 0; s4 < 16; ++s4) av4[s4] = ap[s4];
-    }
-#pragma unroll
-    for (int j = 0; j < 32; ++j) {
-      const int i = tid + 256 * j, t = 2 * j + (tid >> 7);
-      if (t < chunk) dbs[(tid & 127) * tp + t] = (i < n_live) ? fmaxf(stage[j], thr) : 0.0f;
-    }
-    __syncthreads();
-    if (wave < 2) {
-      bd_f32x16 acc;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
-      const float* bp = dbs + h * tp + min(wave * 32 + li, chunk - 1);
-#pragma unroll
-      for (int s4 = 0; s4 < 16; ++s4) {
-        const float a4[4] = {av4[s4].x, av4[s4].y, av4[s4].z, av4[s4].w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], bp[2 * (4 * s4 + e) * tp], acc, 0, 0, 0);
-      }
-      const int t = wave * 32 + li;
-      const int n_out = kNMfcc * L;
-      if (t < tl) {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const int c = (q & 3) + 8 * (q >> 2) + 4 * h;
-          if (c < kNMfcc) {
-            float v = (t < tu) ? acc[q] : 0.0f;
-            const int oo = c * L + t;
-            if (a.aff_mean) v = (float)(((double)v - a.aff_mean[oo]) / a.aff_scale[oo]);
-            a.out[(size_t)u * n_out + oo] = v;
-          }
-        }
-      }
-    }
-  }
+  bd_dct_epilogue<256>(a, ring, ring + 128 * 65, tid, u, n_frames, clip_max);
 }
 
 // ---------------------------------------------------------------------------------------------
