@@ -81,6 +81,16 @@ class TrainPipeline:
         self._warm = False
         self.stream = torch.cuda.Stream(device=self.dev)       # training stream (equal priorities measured best)
         self.mfcc_stream = self._make_mfcc_stream(mfcc_cus)   # feature-extraction stream
+        # When the classifier's stream is IDLE (the first step after a drained pipeline, a host-bound caller), the extraction does
+        # not need to keep to its CU share: it runs on an unmasked stream, 0.19 instead of 0.39 ms for 1024 clips -- in a 20-step
+        # timed region that first extraction is 0.02 ms per step (round 4, scratch/fill_probe.py).  LIPASR_WIDE_WHEN_IDLE=0: off.
+        import os as _os
+
+        self._wide_stream = torch.cuda.Stream(device=self.dev) if (getattr(self, "_masked_stream", None) is not None and not self._custom_ex
+                                                                  and _os.environ.get("LIPASR_WIDE_WHEN_IDLE", "1") == "1") else None
+        self._ev_last_mfcc = None     # the extraction plan's scratch is shared: consecutive extractions are ordered, whatever stream they ran on
+        self._last_train_ev = None
+        self._n_cu = torch.cuda.get_device_properties(self.dev).multi_processor_count
         self._ev_feat = [torch.cuda.Event() for _ in range(self._nbuf)]   # features of buffer b are ready
         self._ev_free = [None] * self._nbuf                             # training has finished reading buffer b
         self._i = 0
@@ -342,11 +352,18 @@ class TrainPipeline:
         # the stream it was allocated on) while the MFCC kernels still read it.  (Not record_stream(): the allocator would
         # then record events on the CU-masked stream whenever such a block is freed -- also after close() destroyed it.)
         caller = torch.cuda.current_stream(self.dev)
+        xs = self.mfcc_stream
+        wide = (self._wide_stream is not None and features is None and (self._last_train_ev is None or self._last_train_ev.query()))
+        if wide:  # nothing runs on the classifier's CUs: this extraction may have them
+            xs = self._wide_stream
+            self.ex.set(1, self._n_cu)
         if self.sync_inputs:
-            self.mfcc_stream.wait_stream(caller)
-        with torch.cuda.stream(self.mfcc_stream):
+            xs.wait_stream(caller)
+        with torch.cuda.stream(xs):
+            if self._ev_last_mfcc is not None and self._wide_stream is not None:
+                xs.wait_event(self._ev_last_mfcc)
             if self._ev_free[b] is not None:
-                self.mfcc_stream.wait_event(self._ev_free[b])  # the step that last read this buffer is done
+                xs.wait_event(self._ev_free[b])  # the step that last read this buffer is done
             if features is not None:
                 self._feats2[b][:bsz].copy_(features)
             else:
@@ -355,7 +372,10 @@ class TrainPipeline:
                 else:
                     self.ex(waves, self.L, self.mean, self.scale, out=self._feats2[b][:bsz])
             self._labels2[b][:bsz].copy_(y_onehot)
-            self._ev_feat[b].record(self.mfcc_stream)
+            self._ev_feat[b].record(xs)
+            self._ev_last_mfcc = self._ev_feat[b]
+        if wide:
+            self.ex.set(1, self.mfcc_cus)
         if self.sync_inputs:
             caller.wait_event(self._ev_feat[b])
         with torch.cuda.stream(self.stream):
@@ -409,8 +429,11 @@ class TrainPipeline:
             ev = torch.cuda.Event()
             ev.record(self.stream)
             self._ev_free[b] = ev
+            self._last_train_ev = ev
 
     def synchronize(self):
+        if getattr(self, "_wide_stream", None) is not None:
+            self._wide_stream.synchronize()
         self.mfcc_stream.synchronize()
         self.stream.synchronize()
 

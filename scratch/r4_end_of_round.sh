@@ -35,7 +35,8 @@ d = out["paths"]["r4_default"]
 out["end_of_round"] = {"stage_bytes_per_utt": d["stage_bytes_per_utt"], "x_algorithmic": d["x_algorithmic"], "source_sha16": bench.mfcc_source_sha()}
 k = d["kernels"].get("stft_bdft_kernel", {})
 if k:
-    out["end_of_round"]["stft_bdft_mfma_busy_frac"] = k.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (4.0 * k.get("SQ_BUSY_CYCLES", 1) ) if k.get("SQ_BUSY_CYCLES") else None
+    # matrix pipe busy per SIMD (256 CUs x 4) over the dispatch's shader cycles (GRBM_GUI_ACTIVE sums the 8 XCDs)
+    out["end_of_round"]["stft_bdft_mfma_busy_frac"] = k.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / 1024.0 / (k["GRBM_GUI_ACTIVE"] / 8.0) if k.get("GRBM_GUI_ACTIVE") else None
 json.dump(out, open("$O/r04_mfcc_pmc.json", "w"), indent=1)
 b = json.load(open("$O/bench_config3.json"))
 print("bench long ", b["value"], b["ms_per_step"], b["train_graph_ms"], b["roofline"]["kernel_ms"], b["roofline"].get("standalone_whole_chip"))
