@@ -382,7 +382,14 @@ int lipasr_mfcc_plan_profile_end(lipasr_mfcc_t p, float* avg_ms3, int* n_calls);
 /* knobs of one plan: keys 0 and 1 as lipasr_debug_set; key 2: value != 0 makes the plan run the fused resample -> STFT
  * kernel for every batch (1.7x the algorithmic HBM bytes instead of 4.6x, but about 1.7x the time of the three-kernel path
  * on a whole MI355X: DESIGN.md section 3); by default the fused kernel runs only where the three-kernel path cannot read
- * the input (int16 or per-clip lengths in rows that are not a multiple of 4 samples long). */
+ * the input (int16 or per-clip lengths in rows that are not a multiple of 4 samples long).
+ * Stage-mask bits of key 0 (2048/512 plans): 256 = the Stockham FFT kernel (stft_mel2_kernel) instead of the block-DFT
+ * kernel on the matrix pipe (stft_bdft_kernel, the default since round 4): its parity reference; 64 = the round-2 kernel.
+ * key 3: frames per workgroup of the block-DFT kernel (a multiple of 4 in [4, 4096]; default 44 = one workgroup per 1-s clip).
+ * key 4: value != 0 lets that kernel apply the top_db floor and the DCT itself when one workgroup covers a whole clip
+ * (<= 64 frames, utterance_length <= 64): no dct_kernel launch, bit-identical features; off by default (slower on batches
+ * that are not cache-warm: DESIGN.md section 3).
+ * Replaces the arithmetic of librosa.feature.mfcc's STFT, extract_features_construct_dataset.py:30. */
 int lipasr_mfcc_plan_set(lipasr_mfcc_t p, int key, int value);
 
 /* A12 audio-domain noise on device, Philox RNG (attacks.py:73-86, 145-183, 222-245), in place on
