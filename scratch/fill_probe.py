@@ -21,8 +21,16 @@ def one(i):
     pipe.step(waves[s:s + B], y[s:s + B])
 for i in range(8): one(i)
 pipe.synchronize(); torch.cuda.synchronize()
+import sys as _s
+spin = int(_s.argv[1]) if len(_s.argv) > 1 else 0   # untimed extractions on a side stream before every timed region
+side = torch.cuda.Stream(device=dev)
 for rep in range(2):
     K = 20
+    if spin:
+        with torch.cuda.stream(side):
+            for k in range(spin):
+                ex(waves[(k % 16) * B:(k % 16 + 1) * B])
+        side.synchronize()
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)]
     host = []
     with torch.cuda.stream(pipe.stream):
