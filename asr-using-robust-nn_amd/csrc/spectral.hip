@@ -157,6 +157,26 @@ __global__ __launch_bounds__(256) void chain_step_kernel(const float* __restrict
   }
 }
 
+// x^(1/m) for x > 0 and a small integer m (the number of layers), to fp64 accuracy without the fp64 pow() (a serial chain of
+// thousands of cycles, six of them in a row per projection): range reduction by frexp, a hardware fp32 log2 / exp2 estimate of
+// the root of the mantissa part (1e-7), two Newton steps on y^m = f (1e-14, 1e-28).
+__device__ __forceinline__ double root_m(double x, int m) {
+  if (!(x > 0.0) || !(x < 1.7e308)) return pow(x, 1.0 / (double)m);  // (zero, negative, inf, nan: the library's answers)
+  int e;
+  double f = frexp(x, &e);  // x = f 2^e, f in [0.5, 1)
+  int q = e / m, r = e - q * m;
+  if (r < 0) { r += m; q -= 1; }
+  f = ldexp(f, r);  // f in [0.5, 2^(m-1)], x = f 2^(q m)
+  double y = (double)exp2f(log2f((float)f) / (float)m);
+#pragma unroll 1
+  for (int it = 0; it < 2; ++it) {
+    double ym = y;
+    for (int k = 1; k < m; ++k) ym *= y;      // y^m
+    y -= y * (1.0 - f / ym) / (double)m;
+  }
+  return ldexp(y, q);
+}
+
 struct OrderArgs {
   int n_layers;
   int n_order;
@@ -238,7 +258,7 @@ __global__ __launch_bounds__(kSigmaThreads) void product_sigma_kernel(const doub
       for (int e = tid; e < RR; e += kSigmaThreads) nxt[e] *= inv;
       __syncthreads();
       double* t = cur; cur = nxt; nxt = t;
-      if (fabs(tj - 1.0) < 1e-15) break;  // rank-1 projector reached: converged (same value in every thread)
+      if (fabs(tj - 1.0) < 1e-12) break;  // rank-1 projector reached (same value in every thread): the squarings left would add < 1e-12 2^-it to log lambda; at 1e-15 rounding noise in the trace kept the loop running all 40 rounds
     }
   }
   if (tid == 0) {
@@ -249,10 +269,9 @@ __global__ __launch_bounds__(kSigmaThreads) void product_sigma_kernel(const doub
       double sc[LIPASR_MAX_LAYERS];
       for (int l = 0; l < oa.n_layers; ++l) sc[l] = 1.0;
       double n = sigma;
-      const double inv_m = 1.0 / (double)oa.n_layers;
       for (int v = 0; v < oa.n_order; ++v) {
         norms_out[v] = (float)n;
-        const double s = pow(rho / (n + kEps), inv_m);
+        const double s = root_m(rho / (n + kEps), oa.n_layers);
         sc[oa.order[v]] *= s;
         n *= s;
       }
@@ -288,6 +307,143 @@ __global__ __launch_bounds__(256) void scale_layers_kernel(LayerPtrs lp, const f
     for (size_t i = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) w[i] *= s;
   } else {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) w[i] *= s;
+  }
+}
+
+// Round 4: the eigenvalue step and the rescaling in ONE launch.  Every workgroup recomputes sigma for itself from the finished
+// product P (R x n, 35 kB for the reference's model: staged in LDS, Gram in fp64, the same normalised squarings as
+// product_sigma_kernel) and then scales its slice of its layer -- identical arithmetic on identical inputs in every workgroup,
+// so all of them apply the same factors.  Replaces product_sigma_kernel (14 us: one workgroup summing 220 cross-XCD Gram
+// partials) + a launch boundary + scale_layers_kernel (8 us) on the critical path of every training step; the chain's last
+// step no longer emits Gram partials for it.  Workgroup (0, 0) also writes scales / norms / sigma and bumps the step counter.
+__global__ __launch_bounds__(256) void sigma_scale_layers_kernel(const float* __restrict__ P, int n, int R, double rho, OrderArgs oa,
+                                                                  LayerPtrs lp, float* __restrict__ scales_out, float* __restrict__ norms_out,
+                                                                  float* __restrict__ sigma_out, int* __restrict__ bump) {
+  extern __shared__ __attribute__((aligned(16))) char ssl_raw[];
+  const int tid = threadIdx.x;
+  const int RR = R * R, total = R * n;
+  // dynamic LDS: A | B | four Gram partials (doubles, R^2 each) | P [R][n] floats: 40 kB for 10 x 880, four workgroups per CU
+  double* A = reinterpret_cast<double*>(ssl_raw);
+  double* B = A + RR;
+  double* gpart0 = B + RR;  // [4][RR]
+  float* Ps = reinterpret_cast<float*>(gpart0 + 4 * RR);
+  __shared__ float sc_s[LIPASR_MAX_LAYERS];
+  if ((total & 3) == 0 && (reinterpret_cast<uintptr_t>(P) & 15) == 0) {
+    const float4* src = reinterpret_cast<const float4*>(P);
+    float4* dst = reinterpret_cast<float4*>(Ps);
+    for (int f = tid; f < (total >> 2); f += 256) dst[f] = src[f];
+  } else {
+    for (int f = tid; f < total; f += 256) Ps[f] = P[f];
+  }
+  __syncthreads();
+  // Gram (symmetric: the R (R + 1) / 2 entries a <= b): wavefront w takes the column quads q = w (mod 4), lane e (and e + 64, ...)
+  // the entry; float4 reads of both rows, fp64 products and sums in ascending column order
+  {
+    const int w = tid >> 6, lane = tid & 63;
+    const int n_ent = R * (R + 1) / 2, nq = n >> 2;
+    for (int e = lane; e < n_ent; e += 64) {
+      int a = 0, rem = e;
+      while (rem >= R - a) { rem -= R - a; ++a; }  // e -> (a, b = a + rem)
+      const int b = a + rem;
+      const float* pa = Ps + (size_t)a * n;
+      const float* pb = Ps + (size_t)b * n;
+      double s = 0.0;
+      if ((n & 3) == 0) {
+        for (int q = w; q < nq; q += 4) {
+          const float4 x = *reinterpret_cast<const float4*>(pa + 4 * q), y = *reinterpret_cast<const float4*>(pb + 4 * q);
+          s = fma((double)x.x, (double)y.x, s); s = fma((double)x.y, (double)y.y, s);
+          s = fma((double)x.z, (double)y.z, s); s = fma((double)x.w, (double)y.w, s);
+        }
+      } else {
+        for (int i = w; i < n; i += 4) s = fma((double)pa[i], (double)pb[i], s);
+      }
+      gpart0[w * RR + a * R + b] = s;
+      gpart0[w * RR + b * R + a] = s;
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < RR; e += 256) A[e] = (gpart0[e] + gpart0[RR + e]) + (gpart0[2 * RR + e] + gpart0[3 * RR + e]);
+  __syncthreads();
+  double t0 = 0.0;
+  for (int a = 0; a < R; ++a) t0 += A[a * R + a];
+  __syncthreads();
+  __shared__ double tj_s[kSquarings + 1];
+  __shared__ double ll_s;
+  const bool zero = !(t0 > 0.0);
+  int n_it = 0;
+  if (!zero) {
+    for (int e = tid; e < RR; e += 256) A[e] /= t0;
+    __syncthreads();
+    // A <- A^2 / tr(A^2).  The traces are kept and their logarithms taken AFTER the loop, all at once (one fp64 log per
+    // squaring inside the loop was a serial chain of ~150 dependent instructions in every workgroup: 6 of the kernel's 22 us)
+    double* cur = A;
+    double* nxt = B;
+    for (int it = 0; it < kSquarings; ++it) {
+      for (int e = tid; e < RR; e += 256) {
+        const int a = e / R, b = e - a * R;
+        double s = 0.0;
+        for (int c = 0; c < R; ++c) s = fma(cur[a * R + c], cur[c * R + b], s);
+        nxt[e] = s;
+      }
+      __syncthreads();
+      double tj = 0.0;
+      for (int a = 0; a < R; ++a) tj += nxt[a * R + a];
+      if (tid == 0) tj_s[it] = tj;
+      n_it = it + 1;
+      const double inv = 1.0 / tj;
+      for (int e = tid; e < RR; e += 256) nxt[e] *= inv;
+      __syncthreads();
+      double* t = cur; cur = nxt; nxt = t;
+      if (fabs(tj - 1.0) < 1e-12) break;  // (the same value in every thread of every workgroup; 1e-15 sat inside the trace's rounding noise: all 40 rounds ran)
+    }
+    // log lambda = log t0 + sum_j 2^-(j+1) log t_j: thread j < n_it takes term j, wavefront 0 sums them in a fixed order
+    if (tid < 64) {
+      double term = 0.0;
+      if (tid < n_it) term = ldexp(log(tj_s[tid]), -(tid + 1));
+      term = wave_sum_d(term);
+      if (tid == 0) ll_s = log(t0) + term;
+    }
+    __syncthreads();
+  }
+  const double log_lambda = zero ? 0.0 : ll_s;
+  if (tid == 0) {
+    const bool first = blockIdx.x == 0 && blockIdx.y == 0;
+    if (first && bump) *bump += 1;
+    const double sigma = zero ? 0.0 : exp(0.5 * log_lambda);
+    if (first && sigma_out) *sigma_out = (float)sigma;
+    double sc[LIPASR_MAX_LAYERS];
+    for (int l = 0; l < oa.n_layers; ++l) sc[l] = 1.0;
+    double nrm = sigma;
+    for (int v = 0; v < oa.n_order; ++v) {
+      if (first) norms_out[v] = (float)nrm;
+      const double s = root_m(rho / (nrm + kEps), oa.n_layers);
+      sc[oa.order[v]] *= s;
+      nrm *= s;
+    }
+    if (first) norms_out[oa.n_order] = (float)nrm;
+    for (int l = 0; l < oa.n_layers; ++l) {
+      sc_s[l] = (float)sc[l];
+      if (first && scales_out) scales_out[l] = (float)sc[l];
+    }
+  }
+  __syncthreads();
+  const int l = blockIdx.y;
+  const float s = sc_s[l];
+  if (s == 1.0f) return;
+  float* w = lp.W[l];
+  const size_t nw = (size_t)lp.rows[l] * lp.cols[l];
+  const size_t stride = (size_t)gridDim.x * 256;
+  if ((reinterpret_cast<uintptr_t>(w) & 15) == 0) {
+    const size_t n4 = nw >> 2;
+    float4* w4 = reinterpret_cast<float4*>(w);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+      float4 x = w4[i];
+      x.x *= s; x.y *= s; x.z *= s; x.w *= s;
+      w4[i] = x;
+    }
+    for (size_t i = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < nw; i += stride) w[i] *= s;
+  } else {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nw; i += stride) w[i] *= s;
   }
 }
 
@@ -511,8 +667,9 @@ static int carve_scratch(lipasr_ctx* h, int R, int max_width, ChainScratch* cs) 
 }
 
 // Launches the chain; on return the Gram partials are in cs.gram (n_part blocks).
+// want_gram = false: the caller takes the finished product itself (*p_final, R x rows[0]) and the last step emits nothing else.
 static int launch_chain(lipasr_ctx* h, const float* const* Ws, const int* rows, const int* cols, int m,
-                        ChainScratch* cs, int* n_part_out, hipStream_t st) {
+                        ChainScratch* cs, int* n_part_out, hipStream_t st, bool want_gram = true, const float** p_final = nullptr) {
   const int R = cols[m - 1];
   if (R > kMaxR) {
     set_error("product chain: last layer has %d outputs; the Gram eigen-solver handles at most %d", R, kMaxR);
@@ -536,7 +693,7 @@ static int launch_chain(lipasr_ctx* h, const float* const* Ws, const int* rows, 
     // step k multiplies by W_k^T: rows of W_k are the new columns of P
     const int n_rows = rows[k];
     const int n_in = (m == 1) ? R : cols[k];
-    const int emit = (k == 0) ? 1 : 0;
+    const int emit = (k == 0 && want_gram) ? 1 : 0;
     const int blocks = (n_rows + kChainRowsPerBlock - 1) / kChainRowsPerBlock;
     const size_t lds = (size_t)R * n_in * sizeof(float) + 4 * kMaxR * sizeof(float) +
                        (emit ? (size_t)4 * R * R * sizeof(double) : 0) + 16;
@@ -561,6 +718,7 @@ static int launch_chain(lipasr_ctx* h, const float* const* Ws, const int* rows, 
 #undef LP_CHAIN
     LP_LAUNCH_CHECK();
     if (emit) *n_part_out = blocks;
+    if (k == 0 && p_final) *p_final = cs->P[cur];
     pin = cs->P[cur];
     p_mode = 0;
     cur ^= 1;
@@ -867,6 +1025,26 @@ int lipasr::project_product_bump(lipasr_handle_t h, float* const* Ws, const int*
   }
   ChainScratch cs;
   int n_part = 0;
+  const int R = cols[n_layers - 1], n0 = rows[0];
+  const size_t lds = (size_t)6 * R * R * sizeof(double) + (size_t)R * n0 * sizeof(float) + 16;
+  if (n_order > 0 && lds <= 96 * 1024) {
+    // the step's critical path: chain -> ONE launch that finds sigma and rescales (every workgroup for itself)
+    const float* p_final = nullptr;
+    rc = launch_chain(h, Ws, rows, cols, n_layers, &cs, &n_part, S(stream), false, &p_final);
+    if (rc != LIPASR_OK) return rc;
+    LayerPtrs lp;
+    lp.n_layers = n_layers;
+    for (int l = 0; l < n_layers; ++l) { lp.W[l] = Ws[l]; lp.rows[l] = rows[l]; lp.cols[l] = cols[l]; }
+    static bool attr_set_dev[16] = {}; int attr_dev = 0; (void)hipGetDevice(&attr_dev); bool& attr_set = attr_set_dev[attr_dev & 15];
+    if (lds > 32 * 1024 && !attr_set) {
+      LP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sigma_scale_layers_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(sigma_scale_layers_kernel, dim3(64, n_layers), dim3(256), lds, S(stream), p_final, n0, R, (double)rho, oa, lp, cs.scales,
+                       norms_out, cs.sigma, bump);
+    LP_LAUNCH_CHECK();
+    return LIPASR_OK;
+  }
   rc = launch_chain(h, Ws, rows, cols, n_layers, &cs, &n_part, S(stream));
   if (rc != LIPASR_OK) return rc;
   hipLaunchKernelGGL(product_sigma_kernel, dim3(1), dim3(kSigmaThreads), 0, S(stream), cs.gram, n_part, cols[n_layers - 1],

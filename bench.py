@@ -170,7 +170,7 @@ def run_config(opt, pool, batch, rank, world, device, steps, warmup, profile):
     pgd = dict(eps=opt.get("pgd_eps", 0.5), eps_step=0.1, max_iter=opt["pgd"]) if opt.get("pgd", 0) > 0 else None
     pipe = TrainPipeline(model, batch=batch, rho=0.1, constraint=opt.get("constraint", "product"), affine=(sc.mean_, sc.scale_), pgd=pgd, dp=dp,
                          use_graph=not opt.get("no_graph"), sync_inputs=False,
-                         mfcc_cus=None if opt.get("pre_extracted") else "auto",  # no extraction stream to keep apart: no CU partition
+                         mfcc_cus=(int(os.environ["LIPASR_PRE_PARTITION"]) if os.environ.get("LIPASR_PRE_PARTITION") else None) if opt.get("pre_extracted") else "auto",  # no extraction stream to keep apart: no CU partition (LIPASR_PRE_PARTITION: A/B probe of the classifier alone on the rest of a partition)
                          overlap_buckets=os.environ.get("LIPASR_DP_OVERLAP", "0") == "1")  # the pool is resident and synchronised before the loop
 
     fused = os.environ.get("LIPASR_MFCC_FUSED", "0") == "1"  # A/B runs: the fused resample -> STFT kernel for every batch
