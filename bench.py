@@ -536,7 +536,8 @@ def main():
         dt5, ex5 = run_config(opt, pool, 512, rank, world, device, args.steps, args.warmup, profile=True)
         out["reference_batch_512"] = {"value": round(512 * args.steps / dt5, 1), "ms_per_step": round(dt5 / args.steps * 1e3, 4),
                                       "mfcc_ms": {k: round(v, 4) for k, v in ex5["mfcc_ms"].items() if k != "calls"},
-                                      "train_graph_ms": round(ex5["train_graph_ms"], 4), "mfcc_stream": ex5.get("mfcc_stream")}
+                                      "train_graph_ms": round(ex5["train_graph_ms"], 4), "event_ms_per_step": round(ex5["event_ms_per_step"], 4),
+                                      "mfcc_stream": ex5.get("mfcc_stream")}
     if world == 1 and not args.skip_other_configs and not (args.pgd or args.pre_extracted or args.bf16):
         # the other single-GPU BASELINE configurations, in the driver-run record (short runs; each is its own model + pipeline)
         k, w = min(args.steps, 50), min(args.warmup, 10)
