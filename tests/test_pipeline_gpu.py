@@ -260,7 +260,8 @@ def test_pgd_pipeline_is_not_slower_as_a_later_pipeline_of_the_process(cuda):
     are multiplexed over GPU_MAX_HW_QUEUES = 4 hardware queues; once enough streams exist it shared a queue with other work and
     its ~440 dependent kernel nodes waited node by node.  TrainPipeline now makes that stream with a full CU mask, which owns a
     hardware queue.  Here: a PGD pipeline timed first, then again after the four kinds of pipeline bench.py builds before it
-    (two CU partitions, pre-extracted fp32 / bf16) have come and gone: within 10 %."""
+    (two CU partitions, pre-extracted fp32 / bf16) have come and gone: 4.08 against 4.05 ms when written; asserted within 30 %
+    (the fault was a factor of three; a shared box moves a 4 ms step by a few per cent)."""
     import time
 
     from lipasr.attacks import StandardScaler
@@ -312,4 +313,4 @@ def test_pgd_pipeline_is_not_slower_as_a_later_pipeline_of_the_process(cuda):
     others = [run(B), run(512), run(B, pre=True), run(B, pre=True, bf16=True)]
     fifth = run(B, pgd=pgd)
     print(f"\nPGD-20 step: {first:.3f} ms as the first pipeline, {fifth:.3f} ms after four others ({[round(o, 3) for o in others]})")
-    assert fifth <= 1.10 * first, (first, fifth)
+    assert fifth <= 1.30 * first, (first, fifth)
