@@ -26,7 +26,7 @@ from .parallel import DataParallel
 
 class TrainPipeline:
     def __init__(self, model, batch, sr_in=16000, n_samp=16000, utterance_length=44, rho=0.1, constraint="product",
-                 affine=None, pgd=None, dp=None, use_graph=True, per_layer_iters=4, extractor=None, mfcc_cus="auto",
+                 affine=None, pgd=None, dp=None, use_graph="auto", per_layer_iters=4, extractor=None, mfcc_cus="auto",
                  sync_inputs=True, overlap_buckets=False, sync_bn=False, train_cus="auto"):
         """constraint: 'product' (simple_norm_constraint, all layers), 'per_layer' (norm_constraint) or None.
         affine: (mean, scale) float64 device tensors [20*utterance_length] or None.
@@ -38,6 +38,13 @@ class TrainPipeline:
         train_cus: "rest" confines the classifier's stream to the CUs the extraction stream does NOT use (a second CU-masked
         stream: the chain's short kernels then never share a CU's LDS, wave slots and L1 with an MFCC workgroup), "all"
         leaves it on every CU, "auto" = "rest" with the built-in MFCC plan.
+        use_graph: replay the classifier's part of a step as HIP graph(s) (True), launch its kernels one by one (False), or
+        "auto": graphs for the long launch sequences (PGD adversarial training: ~440 launches per step; synchronized BatchNorm:
+        one graph per segment between collectives), plain launches for the 29-kernel step -- measured at the end of round 4
+        (batch 1024, MI355X): 0.411 against 0.417 ms per step over 200 steps, 0.433 against 0.444 over the driver's 20 (config 2:
+        0.366 against 0.373).  The host needs 0.25 ms to enqueue a step's launches (0.09 with the graph), so it stays ahead of
+        the GPU either way, and a replayed graph costs the GPU more between nodes than back-to-back launches on one queue do
+        (the same graph under AMD_DIRECT_DISPATCH=0: 0.345 ms in config 2 -- but the two-stream pipeline 0.82).
         sync_inputs: order the extraction stream after the caller's current stream and the caller's stream after the
         extraction (two event hand-offs per step, ~50 us of a 0.4 ms step).  Needed whenever the tensors handed to step()
         were just produced on the caller's stream or are temporaries; a loop over a resident pool that was filled and
@@ -62,7 +69,7 @@ class TrainPipeline:
         model._replica_rank = self.dp.rank  # every rank draws its own dropout masks
         self._late = model.late_floats      # [dW_0 | db_0]: the gradient bucket that is ready last
         self.sync_bn = bool(sync_bn) and self.dp.world > 1
-        self.use_graph = use_graph
+        self.use_graph = (bool(pgd) or self.sync_bn) if use_graph == "auto" else bool(use_graph)
         self.per_layer_iters = per_layer_iters
         self.mean, self.scale = affine if affine is not None else (None, None)
         nf = 20 * self.L

@@ -141,7 +141,7 @@ def make_pool(n_clips, device, seed):
 
 def run_config(opt, pool, batch, rank, world, device, steps, warmup, profile):
     """Builds model + pipeline for one per-GPU batch, times `steps` steps; returns (seconds, extras).
-    opt: dict(constraint=, pgd=, pgd_eps=, bf16=, pre_extracted=, no_graph=)."""
+    opt: dict(constraint=, pgd=, pgd_eps=, bf16=, pre_extracted=, graph="auto"|"on"|"off")."""
     import torch.distributed as dist
 
     import lipasr._native as N
@@ -169,7 +169,7 @@ def run_config(opt, pool, batch, rank, world, device, steps, warmup, profile):
         dp.broadcast(sc.mean_, sc.scale_, model._params, model._bnstate)
     pgd = dict(eps=opt.get("pgd_eps", 0.5), eps_step=0.1, max_iter=opt["pgd"]) if opt.get("pgd", 0) > 0 else None
     pipe = TrainPipeline(model, batch=batch, rho=0.1, constraint=opt.get("constraint", "product"), affine=(sc.mean_, sc.scale_), pgd=pgd, dp=dp,
-                         use_graph=not opt.get("no_graph"), sync_inputs=False,
+                         use_graph={"on": True, "off": False}.get(opt.get("graph", "auto"), "auto"), sync_inputs=False,
                          mfcc_cus=(int(os.environ["LIPASR_PRE_PARTITION"]) if os.environ.get("LIPASR_PRE_PARTITION") else None) if opt.get("pre_extracted") else "auto",  # no extraction stream to keep apart: no CU partition (LIPASR_PRE_PARTITION: A/B probe of the classifier alone on the rest of a partition)
                          overlap_buckets=os.environ.get("LIPASR_DP_OVERLAP", "0") == "1")  # the pool is resident and synchronised before the loop
 
@@ -208,6 +208,7 @@ def run_config(opt, pool, batch, rank, world, device, steps, warmup, profile):
         one(warmup + i)
     with torch.cuda.stream(pipe.stream):
         N.check(N.lib.lipasr_timer_stop(pipe.h.h, tid.value, N.stream_ptr()))
+    t_host = time.perf_counter() - t0  # the host is done enqueueing here; the rest of dt is the GPU catching up
     pipe.synchronize()
     torch.cuda.synchronize()
     if world > 1:
@@ -215,7 +216,7 @@ def run_config(opt, pool, batch, rank, world, device, steps, warmup, profile):
     dt = time.perf_counter() - t0
     ev_ms = C.c_float()
     N.check(N.lib.lipasr_timer_elapsed_ms(pipe.h.h, tid.value, C.byref(ev_ms)))
-    extras = {"event_ms_per_step": ev_ms.value / steps, "final_norm": float(pipe.norms[-1].item()) if opt.get("constraint", "product") == "product" else None,
+    extras = {"event_ms_per_step": ev_ms.value / steps, "host_enqueue_ms_per_step": t_host / steps * 1e3, "final_norm": float(pipe.norms[-1].item()) if opt.get("constraint", "product") == "product" else None,
               "loss": float(model._loss_rows[:batch].mean().item())}
     if profile and pre:
         extras["mfcc_ms"] = {"resample": 0.0, "stft_mel": 0.0, "dct": 0.0, "calls": 0}
@@ -232,6 +233,7 @@ def run_config(opt, pool, batch, rank, world, device, steps, warmup, profile):
         one(warmup + steps + i)
     pipe.synchronize()
     extras["train_graph_ms"] = pipe.train_ms()
+    extras["hip_graph"] = bool(pipe.use_graph)
     extras["allreduce_ms"] = dp.collective_ms()
     extras["comm"] = comm
     standalone = None
@@ -341,7 +343,7 @@ def _short(opt_over, pool, batch, device, steps, warmup):
     of one process; the cause was the training stream sharing a hardware queue (torch pool streams are multiplexed over 4) --
     TrainPipeline now gives it a queue of its own (scratch/pgd_fifth_probe.py: 4.07 ms as the fifth configuration,
     4.09 alone)."""
-    opt = {"constraint": "product", "pgd": 0, "pgd_eps": 0.5, "bf16": False, "pre_extracted": False, "no_graph": False, "int16": False}
+    opt = {"constraint": "product", "pgd": 0, "pgd_eps": 0.5, "bf16": False, "pre_extracted": False, "graph": "auto", "int16": False}
     opt.update(opt_over)
     try:
         sub = (pool[0][:16 * batch], pool[1][:16 * batch])
@@ -392,7 +394,9 @@ def main():
     ap.add_argument("--constraint", default="product", choices=["product", "per_layer", "none"])
     ap.add_argument("--pgd", type=int, default=0, help="PGD iterations per batch (config 5 uses 20)")
     ap.add_argument("--pgd-eps", type=float, default=0.5)
-    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"], help="the classifier's launches as HIP graph(s); auto = the library's "
+                    "choice (TrainPipeline: graphs for PGD / synchronized BatchNorm, plain launches otherwise)")
+    ap.add_argument("--no-graph", action="store_true", help="= --graph off")
     ap.add_argument("--bf16", action="store_true", help="classifier GEMM operands rounded to bf16 at the MFMA, fp32 accumulate (BASELINE config 2's "
                     "arithmetic); the default and the headline are exact fp32")
     ap.add_argument("--pre-extracted", action="store_true", help="BASELINE config 2: train from resident (N,880) features, no MFCC stage")
@@ -404,7 +408,7 @@ def main():
     ap.add_argument("--dry-run-dp", action="store_true", help="rehearse the world > 1 control flow on the CPU (gloo, stand-in replica); prints a line marked dry_run, not a measurement")
     args = ap.parse_args()
     opt = {"constraint": None if args.constraint == "none" else args.constraint, "pgd": args.pgd, "pgd_eps": args.pgd_eps, "bf16": args.bf16,
-           "pre_extracted": args.pre_extracted, "no_graph": args.no_graph, "int16": args.int16}
+           "pre_extracted": args.pre_extracted, "graph": "off" if args.no_graph else args.graph, "int16": args.int16}
 
     from lipasr.parallel import init_from_env
 
@@ -517,13 +521,13 @@ def main():
                                   + " -> Lipschitz-constrained MLP train step (Adam+NonNeg, simple_norm_constraint rho=0.1)" + (f" + PGD-{args.pgd} adversarial inner loop" if args.pgd else "")
                                   + (", data-parallel RCCL gradient all-reduce" if world > 1 else ", 1xMI355X"),
                       "baseline_config": 5 if args.pgd else (2 if args.pre_extracted else (4 if world > 1 else 3)), "global_batch": global_batch, "per_gpu_batch": batch,
-                      "clip": "1 s @ 16 kHz int16 PCM" if args.int16 else "1 s @ 16 kHz fp32", "resident_pool_clips_per_gpu": ex["pool_clips"], "parallelism": f"dp{world}", "hip_graph": not args.no_graph},
+                      "clip": "1 s @ 16 kHz int16 PCM" if args.int16 else "1 s @ 16 kHz fp32", "resident_pool_clips_per_gpu": ex["pool_clips"], "parallelism": f"dp{world}", "hip_graph": ex["hip_graph"]},
            "roofline": roofline, "mfcc_stream": ex.get("mfcc_stream"),
            # CUs of the two CU-masked streams (disjoint): feature extraction | classifier chain
            "cu_partition": {"mfcc": ex.get("mfcc_cus"), "classifier": ex.get("train_cus") or ex.get("n_cus")},
            # the classifier's part of the step (attack + fwd/bwd [+ all-reduce] + Adam + projection), HIP events on the training
            # stream while the next batch's MFCC runs on its own stream; TFLOP/s = 9.59 MFLOP/utt x batch / that time
-           "train_graph_ms": round(ex["train_graph_ms"], 4), "classifier_tflops": round(cls_tflops, 2) if cls_tflops else None,
+           "train_graph_ms": round(ex["train_graph_ms"], 4), "host_enqueue_ms_per_step": round(ex["host_enqueue_ms_per_step"], 4), "classifier_tflops": round(cls_tflops, 2) if cls_tflops else None,
            "classifier_fp32_mfma_frac": round(cls_tflops / FP32_PEAK_TFLOPS, 4) if cls_tflops else None,
            "event_ms_per_step": round(ex["event_ms_per_step"], 4), "final_product_norm": ex["final_norm"], "loss": round(ex["loss"], 4),
            # data parallel: how many ranks the collective backend really reduced over (SUM of ones, not WORLD_SIZE echoed), its
