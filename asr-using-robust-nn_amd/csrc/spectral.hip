@@ -157,6 +157,123 @@ __global__ __launch_bounds__(256) void chain_step_kernel(const float* __restrict
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The first (small) chain steps in ONE launch.  The chain starts at the narrow end of the network: W_m^T is R x 64, the
+// next kernels are 128 x 64, 256 x 128, 512 x 256 -- 0.7 MB of weights and 1.7 M multiply-adds that cost three dependent
+// launches of 6-7 us each (round trips, not work).  Here every workgroup (512 threads) recomputes the leading products
+// P_1 ... P_(n-1) in full in its own LDS and then its own 128 rows of the last fused step, which it writes out; the remaining
+// (large) steps run as chain_step_kernel launches on that output.  Recomputing is only cheap on the matrix pipe: a step is
+// P_next^T [rows x R] = W [rows x n_in] . P^T [n_in x R], one v_mfma_f32_16x16x4_f32 tile per 16 weight rows (exact fp32, an fmaf
+// chain along k; R <= 16 in the tile's columns), the weight fragments of a tile loaded in one go and the next tile's -- of the next
+// step too, they do not depend on P -- fetched while this one multiplies.  (A first version kept chain_step_kernel's
+// arithmetic -- a wavefront per row, ten wave reductions per row -- and was bitwise equal to the separate launches, but
+// 400 rows x 170 instructions per workgroup took 90 us; round 3's version ran all rows through ONE workgroup: +192 us.)
+// The sums are associated differently from chain_step_kernel's, so the product differs from the per-step launches in the
+// last bits (1e-7); every replica runs the same code.
+// ---------------------------------------------------------------------------------------------
+constexpr int kHeadMax = 3;
+constexpr int kHeadQ = 16;   // k-blocks of 16 per tile row: n_in <= 256
+typedef float head_f32x4 __attribute__((ext_vector_type(4)));
+struct ChainHead {
+  int n;                      // fused steps (>= 2)
+  const float* W[kHeadMax];   // step s: n_rows[s] x n_in[s], row-major, n_in a multiple of 16
+  int n_rows[kHeadMax];
+  int n_in[kHeadMax];         // n_in[s + 1] == n_rows[s]
+  const float* Wlast;         // P_0[r][j] = Wlast[j * R + r]
+  int R;                      // <= 16
+  float* Pout;                // R x n_rows[n - 1]
+  int rows_per_block;         // of the last fused step (128: one tile per wavefront)
+};
+
+__device__ __forceinline__ void head_load(const float* __restrict__ W, int n_rows, int n_in, int i0, int lane, float4 (&a)[kHeadQ]) {
+  const int row = i0 + (lane & 15);
+  const float* p = W + (size_t)min(row, n_rows - 1) * n_in + 4 * (lane >> 4);
+#pragma unroll
+  for (int q = 0; q < kHeadQ; ++q) {
+    if (16 * q < n_in) {
+      a[q] = *reinterpret_cast<const float4*>(p + 16 * q);
+      if (row >= n_rows) a[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+}
+
+// one 16-row tile: acc[reg] = P_next[r = lane & 15][i0 + 4 (lane >> 4) + reg].  T: [16][n_in + 4] in LDS, rows >= R zero
+__device__ __forceinline__ head_f32x4 head_tile(const float4 (&a)[kHeadQ], const float* __restrict__ T, int n_in, int lane) {
+  head_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const float* t = T + (lane & 15) * (n_in + 4) + 4 * (lane >> 4);
+#pragma unroll
+  for (int q = 0; q < kHeadQ; ++q) {
+    if (16 * q < n_in) {
+      const float4 b = *reinterpret_cast<const float4*>(t + 16 * q);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].x, b.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].y, b.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].z, b.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].w, b.w, acc, 0, 0, 0);
+    }
+  }
+  return acc;
+}
+
+__global__ __launch_bounds__(512) void chain_head_kernel(ChainHead a) {
+  extern __shared__ __attribute__((aligned(16))) float hs[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int R = a.R;
+  // the tile sequence of this wavefront: step s < n - 1: tiles wave, wave + 8, ... of n_rows[s] / 16; last step: the tiles of this
+  // workgroup's rows.  The first tile's weights start their trip before P_0 is staged.
+  float4 cur[kHeadQ], nxt[kHeadQ];
+  const int last_i0 = blockIdx.x * a.rows_per_block, last_i1 = min(a.n_rows[a.n - 1], last_i0 + a.rows_per_block);
+  auto first_tile = [&](int s) { return (s + 1 < a.n) ? 16 * wave : last_i0 + 16 * wave; };
+  auto end_row = [&](int s) { return (s + 1 < a.n) ? a.n_rows[s] : last_i1; };
+  if (first_tile(0) < end_row(0)) head_load(a.W[0], a.n_rows[0], a.n_in[0], first_tile(0), lane, cur);
+  float* Pin = hs;
+  {
+    const int ld = a.n_in[0] + 4;
+    for (int f = tid; f < 16 * ld; f += 512) Pin[f] = 0.0f;
+    __syncthreads();
+    const int total = R * a.n_in[0];
+    for (int f = tid; f < total; f += 512) {
+      const int j = f / R, r = f - j * R;
+      Pin[r * ld + j] = a.Wlast[f];
+    }
+  }
+  __syncthreads();
+  for (int s = 0; s < a.n; ++s) {
+    const int n_in = a.n_in[s], n_rows = a.n_rows[s];
+    const bool last = (s + 1 == a.n);
+    float* Pnext = Pin + 16 * (n_in + 4);
+    const int ldn = n_rows + 4;
+    if (!last) {  // rows >= R of the next panel stay zero (the tile's columns R .. 15 multiply them)
+      for (int f = tid + R * ldn; f < 16 * ldn; f += 512) Pnext[f] = 0.0f;
+    }
+    const int e = end_row(s);
+    for (int i0 = first_tile(s); i0 < e; i0 += 128) {
+      // the weights of this wavefront's next tile -- of this step, or the first one of the next step
+      const bool more = i0 + 128 < e;
+      if (more) head_load(a.W[s], n_rows, n_in, i0 + 128, lane, nxt);
+      else if (!last && first_tile(s + 1) < end_row(s + 1)) head_load(a.W[s + 1], a.n_rows[s + 1], a.n_in[s + 1], first_tile(s + 1), lane, nxt);
+      const head_f32x4 acc = head_tile(cur, Pin, n_in, lane);
+      const int r = lane & 15, ib = i0 + 4 * (lane >> 4);
+      if (r < R) {
+        if (!last) {
+          *reinterpret_cast<float4*>(Pnext + r * ldn + ib) = make_float4(acc[0], acc[1], acc[2], acc[3]);  // (rows past n_rows: zero weights -> zeros, inside the padding)
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (ib + q < n_rows) a.Pout[(size_t)r * n_rows + ib + q] = acc[q];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < kHeadQ; ++q) cur[q] = nxt[q];
+    }
+    if (!last) {
+      if (!(first_tile(s) < e) && first_tile(s + 1) < end_row(s + 1))  // this wavefront had no tile in step s: nobody fetched its next one
+        head_load(a.W[s + 1], a.n_rows[s + 1], a.n_in[s + 1], first_tile(s + 1), lane, cur);
+      __syncthreads();
+      Pin = Pnext;
+    }
+  }
+}
+
 // x^(1/m) for x > 0 and a small integer m (the number of layers), to fp64 accuracy without the fp64 pow() (a serial chain of
 // thousands of cycles, six of them in a row per projection): range reduction by frexp, a hardware fp32 log2 / exp2 estimate of
 // the root of the mantissa part (1e-7), two Newton steps on y^m = f (1e-14, 1e-28).
@@ -666,6 +783,8 @@ static int carve_scratch(lipasr_ctx* h, int R, int max_width, ChainScratch* cs) 
   return LIPASR_OK;
 }
 
+static int g_chain_head = -1;  // lipasr_debug_chain_head: -1 the two leading steps when legal, 0 none, n > 0 at most n (<= 3)
+
 // Launches the chain; on return the Gram partials are in cs.gram (n_part blocks).
 // want_gram = false: the caller takes the finished product itself (*p_final, R x rows[0]) and the last step emits nothing else.
 static int launch_chain(lipasr_ctx* h, const float* const* Ws, const int* rows, const int* cols, int m,
@@ -688,7 +807,44 @@ static int launch_chain(lipasr_ctx* h, const float* const* Ws, const int* rows, 
     pin = nullptr;
     p_mode = 2;
   }
-  const int first_k = (m == 1) ? 0 : m - 2;
+  int first_k = (m == 1) ? 0 : m - 2;
+  // the leading small steps as one launch (chain_head_kernel): steps first_k ... first_k - n + 1, never the last step (k = 0,
+  // which may emit the Gram partials); R <= 16, panels of <= 256 columns in multiples of 16
+  if (m >= 4 && g_chain_head != 0 && R <= 16) {
+    int n = 0;
+    while (n < kHeadMax && first_k - n >= 1 && cols[first_k - n] <= 16 * kHeadQ && (cols[first_k - n] & 15) == 0 &&
+           (reinterpret_cast<uintptr_t>(Ws[first_k - n]) & 15) == 0)
+      ++n;
+    // measured (MI355X, reference widths, rocprofv3): two fused steps 7.2 us against 2 x 6.2, three 15.5 against 3 x 6.3 (the third
+    // step's 96 extra matrix instructions per wavefront cost 8 us on the 4 CUs the launch occupies): two unless told otherwise
+    if (n > (g_chain_head > 0 ? g_chain_head : 2)) n = (g_chain_head > 0 ? g_chain_head : 2);
+    if (n >= 2) {
+      ChainHead a;
+      memset(&a, 0, sizeof(a));
+      a.n = n;
+      size_t lds_f = 0;
+      for (int s2 = 0; s2 < n; ++s2) {
+        a.W[s2] = Ws[first_k - s2];
+        a.n_rows[s2] = rows[first_k - s2];
+        a.n_in[s2] = cols[first_k - s2];
+        lds_f += (size_t)16 * (a.n_in[s2] + 4);
+      }
+      a.Wlast = Ws[m - 1];
+      a.R = R;
+      a.Pout = cs->P[cur];
+      a.rows_per_block = 128;
+      const int blocks = (a.n_rows[n - 1] + a.rows_per_block - 1) / a.rows_per_block;
+      const size_t lds = lds_f * sizeof(float);
+      if (lds > 48 * 1024)
+        LP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_head_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(chain_head_kernel, dim3(blocks), dim3(512), lds, st, a);
+      LP_LAUNCH_CHECK();
+      pin = cs->P[cur];
+      p_mode = 0;
+      cur ^= 1;
+      first_k -= n;
+    }
+  }
   for (int k = first_k; k >= 0; --k) {
     // step k multiplies by W_k^T: rows of W_k are the new columns of P
     const int n_rows = rows[k];
@@ -962,6 +1118,11 @@ __global__ __launch_bounds__(256) void sv_clip_kernel(const float* __restrict__ 
 using namespace lipasr;
 
 extern "C" {
+
+int lipasr_debug_chain_head(int n) {
+  g_chain_head = n < 0 ? -1 : (n > kHeadMax ? kHeadMax : n);
+  return LIPASR_OK;
+}
 
 int lipasr_sigma_max(lipasr_handle_t h, const float* W, int rows, int cols, float* v_state, int warm, int iters,
                      int clamp_nonneg, float* sigma_out, lipasr_stream_t stream) {

@@ -117,6 +117,7 @@ PROTOTYPES = {
     "lipasr_add_noise_f32": (i32, [c_h, c_f, i32, i32, i32, f32, f32, u64, c_s]),
     "lipasr_debug_set": (i32, [c_h, i32, i32]),
     "lipasr_debug_gemm_mode": (i32, [i32]),
+    "lipasr_debug_chain_head": (i32, [i32]),
     "lipasr_debug_table": (i32, [i32, i32, C.POINTER(f32), i32]),
 }
 
@@ -126,6 +127,8 @@ for _name, (_res, _args) in PROTOTYPES.items():
     _fn.argtypes = _args
 
 
+if os.environ.get("LIPASR_CHAIN_HEAD"):  # A/B timing knob (lipasr_debug_chain_head): same product bit for bit
+    lib.lipasr_debug_chain_head(int(os.environ["LIPASR_CHAIN_HEAD"]))
 if os.environ.get("LIPASR_GEMM_MODE"):  # A/B timing knob (lipasr_debug_gemm_mode): never a different backend
     lib.lipasr_debug_gemm_mode(int(os.environ["LIPASR_GEMM_MODE"]))
 

@@ -413,6 +413,13 @@ int lipasr_debug_set(lipasr_handle_t h, int key, int value);
  * launch on 32x32 register-fragment tiles (round 2) instead of 64x64 LDS tiles. */
 int lipasr_debug_gemm_mode(int mode);
 
+/* Profiling knob: how many of the leading (small) steps of the product chain W_m^T ... W_1^T run as ONE launch
+ * (chain_head_kernel, fp32 matrix instructions): -1 = automatic (the first two steps, when their panels have <= 256 columns
+ * in multiples of 16 and there are at most 16 classes; never the last step), 0 = none (one launch per step, rounds 1-3),
+ * n = 2 or 3 = at most n.
+ * The fused steps associate their sums differently: the product agrees with the per-step launches to ~1e-7. */
+int lipasr_debug_chain_head(int n);
+
 /* Host-only (no GPU needed): copies one constant table, exactly as the kernels read it, into `out`
  * and returns its element count (negative = error); out may be NULL to query the size.
  * which: 0 Hann[2048]; 1 DCT[20*128]; 2 dense mel filter bank[128*1025]; 3 polyphase resampling taps

@@ -10,7 +10,7 @@ cp $f $R/gpurun_out/prof_cfg2_$1_kernel_stats.csv
 python3 - "$f" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-for r in rows[:18]:
+for r in [r for r in rows if "lipasr" in r["Name"]]:
     print(f"{r['Name'][:90]:90s} calls {r['Calls']:>5s} avg {float(r['AverageNs'])/1e3:7.2f} us  min {float(r['MinNs'])/1e3:6.2f}")
 PY
 rm -rf $out

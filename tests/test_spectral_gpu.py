@@ -240,3 +240,37 @@ def test_lip_readouts_on_native_model(cuda):
     bn = [(p.gamma[l], p.mov_var[l]) for l in range(5)]
     ref = R.get_lipschitz_constrained(p.W, bn)
     assert abs(get_lipschitz_constrained(m) - ref) / ref < 5e-5
+
+
+@pytest.mark.parametrize("widths", [inputs.FULL_WIDTHS, [2020, 1024, 512, 256, 128, 64, 20], [300, 100, 64, 32, 16, 5], [300, 130, 70, 33, 17, 5]])
+def test_chain_head_launch_against_one_launch_per_step(cuda, widths):
+    """Round 4: the leading small steps of the product chain W_m^T ... W_1^T run as one launch (chain_head_kernel: every
+    workgroup recomputes the small products in its LDS on the fp32 matrix instruction).  Exact fp32 with another association
+    of the sums than chain_step_kernel's: norms and projected kernels agree with one launch per step (lipasr_debug_chain_head(0))
+    to 2e-6 and with the LAPACK oracle to RTOL, and repeat bit for bit.  Reference widths (2 steps fused by default, 3 on request), Speaker-recognition
+    widths (20 classes: not fused), a ragged last fused step (100 rows) and widths that are no multiples of 16 (not fused)."""
+    from lipasr import _native as N
+    from lipasr.Constraints import simple_norm_constraint
+
+    ws = inputs.nonneg_kernels(widths)
+    res = {}
+    try:
+        for n in (0, -1, 3, -1):
+            N.lib.lipasr_debug_chain_head(n)
+            model = FakeModel(ws)
+            cb = simple_norm_constraint(0.1, [])
+            cb.set_model(model)
+            cb.on_batch_end(0)
+            res.setdefault(n, []).append((cb.last_norms.cpu().numpy().copy(), [l.w.copy() for l in model.layers if "dense" in l.name]))
+    finally:
+        N.lib.lipasr_debug_chain_head(-1)
+    ref, norms = R.simple_norm_constraint_pass(ws, 0.1, [])
+    for n in (0, -1, 3):
+        np.testing.assert_allclose(res[n][0][0], norms, rtol=RTOL)
+        np.testing.assert_allclose(res[n][0][0], res[0][0][0], rtol=2e-6)
+        for a, b, r in zip(res[n][0][1], res[0][0][1], ref):
+            np.testing.assert_allclose(a, b, rtol=2e-6, atol=0)
+            assert rel_err(a, r) < RTOL
+    np.testing.assert_array_equal(res[-1][0][0], res[-1][1][0])
+    for a, b in zip(res[-1][0][1], res[-1][1][1]):
+        np.testing.assert_array_equal(a, b)
