@@ -242,13 +242,15 @@ def test_lip_readouts_on_native_model(cuda):
     assert abs(get_lipschitz_constrained(m) - ref) / ref < 5e-5
 
 
-@pytest.mark.parametrize("widths", [inputs.FULL_WIDTHS, [2020, 1024, 512, 256, 128, 64, 20], [300, 100, 64, 32, 16, 5], [300, 130, 70, 33, 17, 5]])
+@pytest.mark.parametrize("widths", [inputs.FULL_WIDTHS, [2020, 1024, 512, 256, 128, 64, 20], [300, 100, 64, 32, 16, 5], [300, 130, 70, 33, 17, 5],
+                                    [300, 256, 128, 64, 16], [200, 96, 256, 48, 16, 3]])
 def test_chain_head_launch_against_one_launch_per_step(cuda, widths):
     """Round 4: the leading small steps of the product chain W_m^T ... W_1^T run as one launch (chain_head_kernel: every
     workgroup recomputes the small products in its LDS on the fp32 matrix instruction).  Exact fp32 with another association
     of the sums than chain_step_kernel's: norms and projected kernels agree with one launch per step (lipasr_debug_chain_head(0))
     to 2e-6 and with the LAPACK oracle to RTOL, and repeat bit for bit.  Reference widths (2 steps fused by default, 3 on request), Speaker-recognition
-    widths (20 classes: not fused), a ragged last fused step (100 rows) and widths that are no multiples of 16 (not fused)."""
+    widths (20 classes: not fused), a ragged last fused step (100 rows), widths that are no multiples of 16 (not fused), 16 classes (the tile's columns full) and a
+    256-column panel (the widest the fused launch takes)."""
     from lipasr import _native as N
     from lipasr.Constraints import simple_norm_constraint
 
