@@ -119,6 +119,42 @@ int lipasr_timer_elapsed_ms(lipasr_handle_t h, int id, float* ms_host) {
   return LIPASR_OK;
 }
 
+// ------------------------------------------------------------------ device-side ordering between two streams
+// A counter in device memory that one stream raises and another waits for, both as one-wavefront kernels: the dependency never
+// passes through the host or the command processor's event machinery (a hipEventRecord + hipStreamWaitEvent pair per hand-off
+// cost the pipeline 9 us per step).  The wait is bounded: after about timeout_ms it gives up, raises *err and lets the
+// stream continue, so a missing signal shows up as an error code, not as a hung queue.  The two streams must be able to run at
+// the same time (disjoint CU masks, or spare wave slots): the waiting wavefront occupies one slot.
+namespace lipasr {
+__global__ void flag_signal_kernel(int* flag, int value) {
+  if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void flag_wait_kernel(const int* flag, int value, int* err, long long max_ticks) {
+  if (threadIdx.x == 0) {
+    const long long t0 = wall_clock64();  // 100 MHz, constant
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < value) {
+      __builtin_amdgcn_s_sleep(16);
+      if (wall_clock64() - t0 > max_ticks) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
+  }
+}
+}  // namespace lipasr
+
+int lipasr_flag_signal(lipasr_handle_t h, int* flag, int value, lipasr_stream_t stream) {
+  LP_CHECK_ARG(h && flag, "lipasr_flag_signal: null argument");
+  hipLaunchKernelGGL(lipasr::flag_signal_kernel, dim3(1), dim3(64), 0, S(stream), flag, value);
+  LP_LAUNCH_CHECK();
+  return LIPASR_OK;
+}
+
+int lipasr_flag_wait(lipasr_handle_t h, const int* flag, int value, int timeout_ms, int* err, lipasr_stream_t stream) {
+  LP_CHECK_ARG(h && flag && err, "lipasr_flag_wait: null argument");
+  LP_CHECK_ARG(timeout_ms >= 1 && timeout_ms <= 600000, "lipasr_flag_wait: timeout %d ms outside [1, 600000]", timeout_ms);
+  hipLaunchKernelGGL(lipasr::flag_wait_kernel, dim3(1), dim3(64), 0, S(stream), flag, value, err, (long long)timeout_ms * 100000LL);
+  LP_LAUNCH_CHECK();
+  return LIPASR_OK;
+}
+
 // ------------------------------------------------------------------ graphs
 int lipasr_graph_begin(lipasr_handle_t h, lipasr_stream_t stream) {
   LP_CHECK_ARG(h != nullptr, "lipasr_graph_begin: null handle");

@@ -96,8 +96,18 @@ class TrainPipeline:
         self._wide_stream = torch.cuda.Stream(device=self.dev) if (getattr(self, "_masked_stream", None) is not None and not self._custom_ex
                                                                   and _os.environ.get("LIPASR_WIDE_WHEN_IDLE", "1") == "1") else None
         self._ev_last_mfcc = None     # the extraction plan's scratch is shared: consecutive extractions are ordered, whatever stream they ran on
+        self._last_xs = None
         self._last_train_ev = None
         self._n_cu = torch.cuda.get_device_properties(self.dev).multi_processor_count
+        # The two hand-offs between the streams (features of buffer b ready -> classifier; classifier done with buffer b -> next
+        # extraction into it) are device-side counters (lipasr_flag_signal / lipasr_flag_wait: one-wavefront kernels) instead of
+        # hipEventRecord + hipStreamWaitEvent pairs: 0.402 against 0.411 ms per step (round 4, batch 1024, same box back to back;
+        # the event pair costs the classifier's stream two barrier packets and a signal per step).  Needs streams that can run at
+        # the same time whatever the other one holds: the two hardware queues of _make_mfcc_stream.  LIPASR_GPU_FLAGS=0: events.
+        self._flags = None
+        if _os.environ.get("LIPASR_GPU_FLAGS", "1") == "1" and getattr(self, "_masked_train_stream", None) is not None:
+            self._flags = torch.zeros(2 * self._nbuf + 1, dtype=torch.int32, device=self.dev)  # ready[b] | free[b] | a wait gave up
+            self._flag_timeout_ms = int(_os.environ.get("LIPASR_FLAG_TIMEOUT_MS", "30000"))  # what a wait sits out before it reports
         self._ev_feat = [torch.cuda.Event() for _ in range(self._nbuf)]   # features of buffer b are ready
         self._ev_free = [None] * self._nbuf                             # training has finished reading buffer b
         self._i = 0
@@ -360,16 +370,25 @@ class TrainPipeline:
         # then record events on the CU-masked stream whenever such a block is freed -- also after close() destroyed it.)
         caller = torch.cuda.current_stream(self.dev)
         xs = self.mfcc_stream
-        wide = (self._wide_stream is not None and features is None and (self._last_train_ev is None or self._last_train_ev.query()))
+        idle = self.stream.query() if self._flags is not None else (self._last_train_ev is None or self._last_train_ev.query())
+        wide = self._wide_stream is not None and features is None and idle
         if wide:  # nothing runs on the classifier's CUs: this extraction may have them
             xs = self._wide_stream
             self.ex.set(1, self._n_cu)
         if self.sync_inputs:
             xs.wait_stream(caller)
         with torch.cuda.stream(xs):
-            if self._ev_last_mfcc is not None and self._wide_stream is not None:
+            if self._flags is not None:
+                if self._last_xs is not None and self._last_xs is not xs:
+                    xs.wait_stream(self._last_xs)  # the plan's scratch is shared: order this extraction after the last one on the other stream
+                self._last_xs = xs
+            elif self._ev_last_mfcc is not None and self._wide_stream is not None:
                 xs.wait_event(self._ev_last_mfcc)
-            if self._ev_free[b] is not None:
+            if self._flags is not None:
+                fl = self._flags
+                if self._i > self._nbuf:
+                    N.check(N.lib.lipasr_flag_wait(self.h.h, fl[self._nbuf + b:].data_ptr(), self._i - self._nbuf, self._flag_timeout_ms, fl[2 * self._nbuf:].data_ptr(), N.stream_ptr()))
+            elif self._ev_free[b] is not None:
                 xs.wait_event(self._ev_free[b])  # the step that last read this buffer is done
             if features is not None:
                 self._feats2[b][:bsz].copy_(features)
@@ -379,15 +398,24 @@ class TrainPipeline:
                 else:
                     self.ex(waves, self.L, self.mean, self.scale, out=self._feats2[b][:bsz])
             self._labels2[b][:bsz].copy_(y_onehot)
-            self._ev_feat[b].record(xs)
-            self._ev_last_mfcc = self._ev_feat[b]
+            if self._flags is not None:
+                N.check(N.lib.lipasr_flag_signal(self.h.h, self._flags[b:].data_ptr(), self._i, N.stream_ptr()))
+            else:
+                self._ev_feat[b].record(xs)
+                self._ev_last_mfcc = self._ev_feat[b]
         if wide:
             self.ex.set(1, self.mfcc_cus)
         if self.sync_inputs:
-            caller.wait_event(self._ev_feat[b])
+            if self._flags is not None:
+                caller.wait_stream(xs)
+            else:
+                caller.wait_event(self._ev_feat[b])
         with torch.cuda.stream(self.stream):
             self._warm_start()
-            self.stream.wait_event(self._ev_feat[b])
+            if self._flags is not None:
+                N.check(N.lib.lipasr_flag_wait(self.h.h, self._flags[b:].data_ptr(), self._i, self._flag_timeout_ms, self._flags[2 * self._nbuf:].data_ptr(), N.stream_ptr()))
+            else:
+                self.stream.wait_event(self._ev_feat[b])
             prof = None
             if getattr(self, "_prof", None) is not None and self._prof_i < len(self._prof):
                 prof = self._prof[self._prof_i]
@@ -433,16 +461,22 @@ class TrainPipeline:
                     N.check(N.lib.lipasr_graph_launch(self.h.h, g[1], N.stream_ptr()))
             if prof is not None:
                 prof[1].record(self.stream)
-            ev = torch.cuda.Event()
-            ev.record(self.stream)
-            self._ev_free[b] = ev
-            self._last_train_ev = ev
+            if self._flags is not None:
+                N.check(N.lib.lipasr_flag_signal(self.h.h, self._flags[self._nbuf + b:].data_ptr(), self._i, N.stream_ptr()))
+            else:
+                ev = torch.cuda.Event()
+                ev.record(self.stream)
+                self._ev_free[b] = ev
+                self._last_train_ev = ev
 
     def synchronize(self):
         if getattr(self, "_wide_stream", None) is not None:
             self._wide_stream.synchronize()
         self.mfcc_stream.synchronize()
         self.stream.synchronize()
+        if getattr(self, "_flags", None) is not None and int(self._flags[-1].item()):
+            raise RuntimeError(f"TrainPipeline: a device-side wait between the extraction and the classifier stream gave up after {self._flag_timeout_ms} ms "
+                               "(the other stream never signalled); results since then are not ordered")
 
     @property
     def mfcc_stream_kind(self):

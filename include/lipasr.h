@@ -67,6 +67,14 @@ int lipasr_timer_stop(lipasr_handle_t h, int timer_id, lipasr_stream_t stream);
 /* synchronises on the stop event; host float out */
 int lipasr_timer_elapsed_ms(lipasr_handle_t h, int timer_id, float* ms_host);
 
+/* Device-side ordering between two streams: `flag` is an int in device memory (start at 0, raise monotonically).
+ * lipasr_flag_signal stores `value` when the stream reaches it; lipasr_flag_wait holds its stream until *flag >= value (a
+ * one-wavefront kernel that polls; after timeout_ms it sets *err = 1, a device int, and lets the stream go on: a missing signal
+ * is an error code, never a hung queue).  Cheaper on the waiting stream than hipEventRecord + hipStreamWaitEvent.  The two
+ * streams must be able to run concurrently (e.g. disjoint CU masks, or spare wave slots: the waiting wavefront holds one). */
+int lipasr_flag_signal(lipasr_handle_t h, int* flag, int value, lipasr_stream_t stream);
+int lipasr_flag_wait(lipasr_handle_t h, const int* flag, int value, int timeout_ms, int* err, lipasr_stream_t stream);
+
 /* HIP-graph capture of any sequence of launch functions issued on `stream`. */
 int lipasr_graph_begin(lipasr_handle_t h, lipasr_stream_t stream);
 int lipasr_graph_end(lipasr_handle_t h, lipasr_stream_t stream, int* graph_id);

@@ -314,3 +314,62 @@ def test_pgd_pipeline_is_not_slower_as_a_later_pipeline_of_the_process(cuda):
     fifth = run(B, pgd=pgd)
     print(f"\nPGD-20 step: {first:.3f} ms as the first pipeline, {fifth:.3f} ms after four others ({[round(o, 3) for o in others]})")
     assert fifth <= 1.30 * first, (first, fifth)
+
+
+def test_device_flag_handoffs_equal_event_handoffs_and_report_a_missing_signal(cuda, monkeypatch):
+    """Round 4: the two hand-offs between the extraction stream and the classifier stream are device-side counters
+    (lipasr_flag_signal / lipasr_flag_wait) by default.  Same kernels in the same order on each stream => the same bits as with
+    hipEventRecord + hipStreamWaitEvent (LIPASR_GPU_FLAGS=0), also when a buffer is reused many times.  And the wait is bounded:
+    a counter nobody raises makes lipasr_flag_wait give up after its timeout and set the error word instead of hanging the queue;
+    a counter that is raised later on another stream releases it."""
+    import time
+
+    from lipasr import _native as N
+    from lipasr.pipeline import TrainPipeline
+    from lipasr.synth import synth_clips
+
+    spec = P.vd_constrained_spec()
+    p = P.init_params(spec, seed=9, dtype=np.float32, nonneg_init=True)
+    waves, labels = synth_clips(192, seed=31)
+    wt = dev(waves)
+    yt = dev(P.to_categorical(labels, 10))
+    results = []
+    for flags in ("0", "1"):
+        monkeypatch.setenv("LIPASR_GPU_FLAGS", flags)
+        m = build_model(spec, max_batch=64)
+        load_params(m, p)
+        pipe = TrainPipeline(m, batch=64, rho=0.1, constraint="product", sync_inputs=False)
+        assert (pipe._flags is not None) == (flags == "1")
+        for rep in range(4):
+            for s in range(0, 192, 64):
+                pipe.step(wt[s:s + 64], yt[s:s + 64])
+        pipe.synchronize()
+        results.append((m._params.clone(), m._bnstate.clone(), pipe.norms.clone(), int(m._step.item())))
+        pipe.close()
+    assert results[0][3] == results[1][3] == 12
+    for a, b in zip(results[0][:3], results[1][:3]):
+        assert torch.equal(a, b)
+
+    h = N.get_handle(0)
+    flag = torch.zeros(2, dtype=torch.int32, device="cuda")
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    # (1) raised later, on another stream: the waiting stream goes on, no error
+    with torch.cuda.stream(s1):
+        N.check(N.lib.lipasr_flag_wait(h.h, flag.data_ptr(), 3, 20000, flag[1:].data_ptr(), N.stream_ptr()))
+        after = torch.ones(1, device="cuda") * 2
+    time.sleep(0.05)
+    assert not s1.query()
+    with torch.cuda.stream(s2):
+        N.check(N.lib.lipasr_flag_signal(h.h, flag.data_ptr(), 3, N.stream_ptr()))
+    s1.synchronize()
+    assert flag.tolist() == [3, 0] and float(after.item()) == 2.0
+    # (2) never raised: gives up after the timeout and says so
+    t0 = time.perf_counter()
+    with torch.cuda.stream(s1):
+        N.check(N.lib.lipasr_flag_wait(h.h, flag.data_ptr(), 4, 50, flag[1:].data_ptr(), N.stream_ptr()))
+    s1.synchronize()
+    dt = time.perf_counter() - t0
+    assert flag.tolist() == [3, 1]
+    assert 0.04 < dt < 2.0, dt
+    assert N.lib.lipasr_flag_wait(h.h, flag.data_ptr(), 4, 0, flag[1:].data_ptr(), N.stream_ptr()) == N.EINVAL
