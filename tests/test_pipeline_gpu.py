@@ -333,22 +333,23 @@ def test_device_flag_handoffs_equal_event_handoffs_and_report_a_missing_signal(c
     waves, labels = synth_clips(192, seed=31)
     wt = dev(waves)
     yt = dev(P.to_categorical(labels, 10))
-    results = []
-    for flags in ("0", "1"):
-        monkeypatch.setenv("LIPASR_GPU_FLAGS", flags)
-        m = build_model(spec, max_batch=64)
-        load_params(m, p)
-        pipe = TrainPipeline(m, batch=64, rho=0.1, constraint="product", sync_inputs=False)
-        assert (pipe._flags is not None) == (flags == "1")
-        for rep in range(4):
-            for s in range(0, 192, 64):
-                pipe.step(wt[s:s + 64], yt[s:s + 64])
-        pipe.synchronize()
-        results.append((m._params.clone(), m._bnstate.clone(), pipe.norms.clone(), int(m._step.item())))
-        pipe.close()
-    assert results[0][3] == results[1][3] == 12
-    for a, b in zip(results[0][:3], results[1][:3]):
-        assert torch.equal(a, b)
+    for pgd in (None, dict(eps=0.5, eps_step=0.1, max_iter=5)):  # (PGD: the classifier's stream keeps every CU, graphs)
+        results = []
+        for flags in ("0", "1"):
+            monkeypatch.setenv("LIPASR_GPU_FLAGS", flags)
+            m = build_model(spec, max_batch=64)
+            load_params(m, p)
+            pipe = TrainPipeline(m, batch=64, rho=0.1, constraint="product", sync_inputs=False, pgd=pgd)
+            assert (pipe._flags is not None) == (flags == "1")
+            for rep in range(4):
+                for s in range(0, 192, 64):
+                    pipe.step(wt[s:s + 64], yt[s:s + 64])
+            pipe.synchronize()
+            results.append((m._params.clone(), m._bnstate.clone(), pipe.norms.clone(), int(m._step.item())))
+            pipe.close()
+        assert results[0][3] == results[1][3] == 12
+        for a, b in zip(results[0][:3], results[1][:3]):
+            assert torch.equal(a, b)
 
     h = N.get_handle(0)
     flag = torch.zeros(2, dtype=torch.int32, device="cuda")
