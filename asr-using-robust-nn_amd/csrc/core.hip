@@ -21,7 +21,7 @@ using namespace lipasr;
 
 extern "C" {
 
-int lipasr_version(void) { return 300; }  // round 3
+int lipasr_version(void) { return 500; }  // round 5 (round 4 added lipasr_flag_*, lipasr_debug_chain_head; round 5: see include/lipasr.h)
 
 const char* lipasr_last_error(void) { return g_err; }
 
@@ -122,19 +122,32 @@ int lipasr_timer_elapsed_ms(lipasr_handle_t h, int id, float* ms_host) {
 // ------------------------------------------------------------------ device-side ordering between two streams
 // A counter in device memory that one stream raises and another waits for, both as one-wavefront kernels: the dependency never
 // passes through the host or the command processor's event machinery (a hipEventRecord + hipStreamWaitEvent pair per hand-off
-// cost the pipeline 9 us per step).  The wait is bounded: after about timeout_ms it gives up, raises *err and lets the
-// stream continue, so a missing signal shows up as an error code, not as a hung queue.  The two streams must be able to run at
-// the same time (disjoint CU masks, or spare wave slots): the waiting wavefront occupies one slot.
+// cost the pipeline 9 us per step).  A wait REPORTS after timeout_ms (*err = 1; `err` may be pinned host memory, so
+// the host sees it without synchronising anything) and KEEPS WAITING -- round 4 let the stream go on at that point, i.e. onto
+// data the other stream had not finished: an ordering guarantee must not turn into a best effort because a peer sat
+// in a long collective or a serialising profiler ran.  Only after kFlagHardFactor x timeout_ms does it give up (*err = 2), so that
+// a signal that can never come (a bug, a destroyed stream) still drains the queue instead of hanging the GPU; and a wait that
+// finds *err already at 2 leaves at once: after one abandoned wait nothing later on that pipeline is ordered, the host is
+// expected to have raised long before.  The two streams must be able to run at the same time (disjoint CU masks, or spare
+// wave slots): the waiting wavefront occupies one slot.
 namespace lipasr {
+constexpr long long kFlagHardFactor = 4;
 __global__ void flag_signal_kernel(int* flag, int value) {
   if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
-__global__ void flag_wait_kernel(const int* flag, int value, int* err, long long max_ticks) {
+__global__ void flag_wait_kernel(const int* flag, int value, int* err, long long soft_ticks) {
   if (threadIdx.x == 0) {
     const long long t0 = wall_clock64();  // 100 MHz, constant
+    bool reported = false;
     while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < value) {
       __builtin_amdgcn_s_sleep(16);
-      if (wall_clock64() - t0 > max_ticks) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      const long long dt = wall_clock64() - t0;
+      if (!reported && dt > soft_ticks) {
+        if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= 2) break;  // an earlier wait was abandoned
+        __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        reported = true;
+      }
+      if (dt > kFlagHardFactor * soft_ticks) { __hip_atomic_store(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
     }
   }
 }
@@ -149,7 +162,7 @@ int lipasr_flag_signal(lipasr_handle_t h, int* flag, int value, lipasr_stream_t 
 
 int lipasr_flag_wait(lipasr_handle_t h, const int* flag, int value, int timeout_ms, int* err, lipasr_stream_t stream) {
   LP_CHECK_ARG(h && flag && err, "lipasr_flag_wait: null argument");
-  LP_CHECK_ARG(timeout_ms >= 1 && timeout_ms <= 600000, "lipasr_flag_wait: timeout %d ms outside [1, 600000]", timeout_ms);
+  LP_CHECK_ARG(timeout_ms >= 1 && timeout_ms <= 150000, "lipasr_flag_wait: timeout %d ms outside [1, 150000]", timeout_ms);
   hipLaunchKernelGGL(lipasr::flag_wait_kernel, dim3(1), dim3(64), 0, S(stream), flag, value, err, (long long)timeout_ms * 100000LL);
   LP_LAUNCH_CHECK();
   return LIPASR_OK;

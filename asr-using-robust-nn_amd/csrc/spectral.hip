@@ -356,15 +356,20 @@ __global__ __launch_bounds__(kSigmaThreads) void product_sigma_kernel(const doub
     for (int e = tid; e < RR; e += kSigmaThreads) A[e] /= t0;
     __syncthreads();
     double wgt = 0.5;
-    // A <- A^2 / tr(A^2): two barriers per squaring, every thread forms the trace itself (no serial section)
+    // A <- A^2 / tr(A^2), ONE barrier per squaring and no in-place write: the buffers keep the UNnormalised square and the
+    // factor 1 / tr of the previous round is applied (squared) when the next square is formed.  Every thread forms the trace
+    // itself from a buffer nobody writes until all threads have passed the next barrier (round 4's form rescaled `nxt` in
+    // place right after the trace reads, with no barrier between them: a wavefront that was late reading the diagonal saw a
+    // mix of scaled and unscaled entries -- ADVICE r4).
     double* cur = A;
     double* nxt = B;
+    double c2 = 1.0;  // (1 / trace of `cur`)^2; A was normalised above
     for (int it = 0; it < kSquarings; ++it) {
       for (int e = tid; e < RR; e += kSigmaThreads) {
         const int a = e / R, b = e - a * R;
         double s = 0.0;
         for (int c = 0; c < R; ++c) s = fma(cur[a * R + c], cur[c * R + b], s);
-        nxt[e] = s;
+        nxt[e] = s * c2;
       }
       __syncthreads();
       double tj = 0.0;
@@ -372,8 +377,7 @@ __global__ __launch_bounds__(kSigmaThreads) void product_sigma_kernel(const doub
       log_lambda += wgt * log(tj);
       wgt *= 0.5;
       const double inv = 1.0 / tj;
-      for (int e = tid; e < RR; e += kSigmaThreads) nxt[e] *= inv;
-      __syncthreads();
+      c2 = inv * inv;
       double* t = cur; cur = nxt; nxt = t;
       if (fabs(tj - 1.0) < 1e-12) break;  // rank-1 projector reached (same value in every thread): the squarings left would add < 1e-12 2^-it to log lambda; at 1e-15 rounding noise in the trace kept the loop running all 40 rounds
     }
@@ -493,14 +497,18 @@ __global__ __launch_bounds__(256) void sigma_scale_layers_kernel(const float* __
     __syncthreads();
     // A <- A^2 / tr(A^2).  The traces are kept and their logarithms taken AFTER the loop, all at once (one fp64 log per
     // squaring inside the loop was a serial chain of ~150 dependent instructions in every workgroup: 6 of the kernel's 22 us)
+    // One barrier per squaring and no in-place write (see product_sigma_kernel): the buffers keep the unnormalised square, the
+    // previous round's 1 / trace is applied, squared, where the next square is formed; a buffer is rewritten only after every
+    // thread has passed the barrier behind its last reader.
     double* cur = A;
     double* nxt = B;
+    double c2 = 1.0;
     for (int it = 0; it < kSquarings; ++it) {
       for (int e = tid; e < RR; e += 256) {
         const int a = e / R, b = e - a * R;
         double s = 0.0;
         for (int c = 0; c < R; ++c) s = fma(cur[a * R + c], cur[c * R + b], s);
-        nxt[e] = s;
+        nxt[e] = s * c2;
       }
       __syncthreads();
       double tj = 0.0;
@@ -508,8 +516,7 @@ __global__ __launch_bounds__(256) void sigma_scale_layers_kernel(const float* __
       if (tid == 0) tj_s[it] = tj;
       n_it = it + 1;
       const double inv = 1.0 / tj;
-      for (int e = tid; e < RR; e += 256) nxt[e] *= inv;
-      __syncthreads();
+      c2 = inv * inv;
       double* t = cur; cur = nxt; nxt = t;
       if (fabs(tj - 1.0) < 1e-12) break;  // (the same value in every thread of every workgroup; 1e-15 sat inside the trace's rounding noise: all 40 rounds ran)
     }

@@ -617,7 +617,13 @@ int launch_stft_bdft(const StftArgs& st, const BdftTables& t, int batch, int seg
   seg_frames = std::max(4, (seg_frames + 3) & ~3);
   a.seg_frames = seg_frames;
   const size_t lds = (size_t)kBdLdsFloats * sizeof(float);
-  LP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(stft_bdft_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  static bool attr_set_dev[16] = {};  // per device, as the GEMM launchers do (round 4 set the attribute on every launch: ADVICE r4)
+  int attr_dev = 0;
+  (void)hipGetDevice(&attr_dev);
+  if (!attr_set_dev[attr_dev & 15]) {
+    LP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(stft_bdft_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set_dev[attr_dev & 15] = true;
+  }
   hipLaunchKernelGGL(stft_bdft_kernel, dim3((st.n_frames + seg_frames - 1) / seg_frames, batch), dim3(256), lds, stream, a);
   LP_LAUNCH_CHECK();
   return LIPASR_OK;

@@ -86,6 +86,8 @@ class TrainPipeline:
         self.v_state = torch.zeros(sum(model._widths[1:]), device=self.dev)
         self._order = N.int_array(list(range(nl)))
         self._warm = False
+        self._masked_stream = self._masked_train_stream = None  # CU-masked streams this pipeline made (hardware queues of their own)
+        self._gemm_tiles_set = False
         self.stream = torch.cuda.Stream(device=self.dev)       # training stream (equal priorities measured best)
         self.mfcc_stream = self._make_mfcc_stream(mfcc_cus)   # feature-extraction stream
         # When the classifier's stream is IDLE (the first step after a drained pipeline, a host-bound caller), the extraction does
@@ -93,7 +95,7 @@ class TrainPipeline:
         # timed region that first extraction is 0.02 ms per step (round 4, scratch/fill_probe.py).  LIPASR_WIDE_WHEN_IDLE=0: off.
         import os as _os
 
-        self._wide_stream = torch.cuda.Stream(device=self.dev) if (getattr(self, "_masked_stream", None) is not None and not self._custom_ex
+        self._wide_stream = torch.cuda.Stream(device=self.dev) if (self._masked_stream is not None and not self._custom_ex
                                                                   and _os.environ.get("LIPASR_WIDE_WHEN_IDLE", "1") == "1") else None
         self._ev_last_mfcc = None     # the extraction plan's scratch is shared: consecutive extractions are ordered, whatever stream they ran on
         self._last_xs = None
@@ -101,12 +103,23 @@ class TrainPipeline:
         self._n_cu = torch.cuda.get_device_properties(self.dev).multi_processor_count
         # The two hand-offs between the streams (features of buffer b ready -> classifier; classifier done with buffer b -> next
         # extraction into it) are device-side counters (lipasr_flag_signal / lipasr_flag_wait: one-wavefront kernels) instead of
-        # hipEventRecord + hipStreamWaitEvent pairs: 0.402 against 0.411 ms per step (round 4, batch 1024, same box back to back;
-        # the event pair costs the classifier's stream two barrier packets and a signal per step).  Needs streams that can run at
-        # the same time whatever the other one holds: the two hardware queues of _make_mfcc_stream.  LIPASR_GPU_FLAGS=0: events.
+        # hipEventRecord + hipStreamWaitEvent pairs: 0.405 against 0.409 ms per step (round 4, batch 1024, same box back to back;
+        # config 5 3.84 against 4.05-4.09 ms).  Needs streams that can run at the same time whatever the other one holds: the two
+        # hardware queues of _make_mfcc_stream.  Round 5: a wait that times out REPORTS and keeps
+        # waiting (it used to let the stream run on onto unordered data); the report lands in a pinned host word that step(),
+        # synchronize() and close() read without synchronising anything, so a caller that never calls pipe.synchronize() hears of
+        # it at its next step; and the default is events whenever ranks exchange gradients or BatchNorm sums (a rank sitting in a
+        # collective while a peer checkpoints is a legitimate stall, and the flag kernels have never run beside an RCCL kernel:
+        # no N > 1 run exists).  LIPASR_GPU_FLAGS=1 forces the flags on, 0 forces events (needed under tools that serialise
+        # kernels across streams, e.g. rocprofv3 --pmc: a wait kernel would spin in front of the signal it waits for).
         self._flags = None
-        if _os.environ.get("LIPASR_GPU_FLAGS", "1") == "1" and getattr(self, "_masked_train_stream", None) is not None:
-            self._flags = torch.zeros(2 * self._nbuf + 1, dtype=torch.int32, device=self.dev)  # ready[b] | free[b] | a wait gave up
+        self._flag_err = None
+        want_flags = _os.environ.get("LIPASR_GPU_FLAGS", "auto")
+        if want_flags == "auto":
+            want_flags = "1" if (self.dp.world == 1 and not self.sync_bn) else "0"
+        if want_flags == "1" and self._masked_train_stream is not None:
+            self._flags = torch.zeros(2 * self._nbuf, dtype=torch.int32, device=self.dev)  # ready[b] | free[b]
+            self._flag_err = torch.zeros(1, dtype=torch.int32).pin_memory()                # 1: a wait is overdue, 2: a wait gave up
             self._flag_timeout_ms = int(_os.environ.get("LIPASR_FLAG_TIMEOUT_MS", "30000"))  # what a wait sits out before it reports
         self._ev_feat = [torch.cuda.Event() for _ in range(self._nbuf)]   # features of buffer b are ready
         self._ev_free = [None] * self._nbuf                             # training has finished reading buffer b
@@ -156,6 +169,11 @@ class TrainPipeline:
                 else:
                     mfcc_cus = n_cu // 2
         if not mfcc_cus or mfcc_cus >= n_cu:
+            # no partition -- but a long dependent chain (the PGD graph: ~440 nodes) still must not sit on a pool stream that may
+            # share a hardware queue with the extraction's pool stream (the cause of round 3's 3x; ADVICE r4: this fix used to
+            # be reachable only through the masked-MFCC branch below)
+            if self.pgd:
+                self._own_queue_train_stream(n_cu)
             return torch.cuda.Stream(device=self.dev)
         # Measured on MI355X (scratch/cu_mask_probe.py): mask bits act in groups of 8 consecutive bits -- group g
         # (bits 8g .. 8g+7) stands for CU g of every XCD, and the group is enabled when any of its bits is set.  So the
@@ -178,6 +196,8 @@ class TrainPipeline:
             import warnings
 
             warnings.warn(f"lipasr: CU-masked stream unavailable ({N.last_error()}); the MFCC stream shares every CU")
+            if self.pgd:
+                self._own_queue_train_stream(n_cu)
             return torch.cuda.Stream(device=self.dev)
         self._masked_stream = st
         # the three-kernel path's persistent resampler sizes its grid to one workgroup per CU it may use
@@ -202,21 +222,44 @@ class TrainPipeline:
                 # 128 tiles): -16 us on the classifier's graph at 160 CUs (PGD, which keeps every CU, loses 8 % with it)
                 N.check(N.lib.lipasr_mlp_set_gemm_tiles(self.model._plan, 128))
                 self._gemm_tiles_set = True  # the pipeline owns this setting: close() puts the model's plan back
-        elif os.environ.get("LIPASR_TRAIN_OWN_QUEUE", "1") == "1":
-            # The classifier keeps every CU (PGD, custom extractor, train_cus="all") -- but NOT on a stream of torch's pool: pool
-            # streams are multiplexed over GPU_MAX_HW_QUEUES (4) hardware queues, and once enough streams exist in the process the
-            # training stream can land on the queue that carries the MFCC stream's kernels; its 440-node PGD graph then waited
-            # behind them node by node: 13.0 ms per step instead of 4.1 as the fifth configuration of one process (round 3's
-            # unexplained 3x; round 4: scratch/pgd_fifth_probe.py, gone with GPU_MAX_HW_QUEUES=8).  A stream made with a FULL CU
-            # mask owns a hardware queue like the two partition streams do.
-            mask2 = (C.c_uint32 * words)()
-            for b in range(n_cu):
-                mask2[b // 32] |= 1 << (b % 32)
-            st2 = N.c_s()
-            if N.lib.lipasr_stream_create_masked(self.h.h, mask2, words, C.byref(st2)) == N.OK:
-                self._masked_train_stream = st2
-                self.stream = torch.cuda.ExternalStream(st2.value, device=self.dev)
+        else:
+            self._own_queue_train_stream(n_cu)
         return torch.cuda.ExternalStream(st.value, device=self.dev)
+
+    def _own_queue_train_stream(self, n_cu):
+        """The classifier keeps every CU (PGD, custom extractor, train_cus="all") -- but NOT on a stream of torch's pool: pool
+        streams are multiplexed over GPU_MAX_HW_QUEUES (4) hardware queues, and once enough streams exist in the process the
+        training stream can land on the queue that carries the MFCC stream's kernels; its 440-node PGD graph then waited
+        behind them node by node: 13.0 ms per step instead of 4.1 as the fifth configuration of one process (round 3's
+        unexplained 3x; round 4: scratch/pgd_fifth_probe.py, gone with GPU_MAX_HW_QUEUES=8).  A stream made with a FULL CU
+        mask owns a hardware queue like the two partition streams do."""
+        import os
+
+        if os.environ.get("LIPASR_TRAIN_OWN_QUEUE", "1") != "1":
+            return
+        words = (n_cu + 31) // 32
+        mask2 = (C.c_uint32 * words)()
+        for b in range(n_cu):
+            mask2[b // 32] |= 1 << (b % 32)
+        st2 = N.c_s()
+        if N.lib.lipasr_stream_create_masked(self.h.h, mask2, words, C.byref(st2)) == N.OK:
+            self._masked_train_stream = st2
+            self.stream = torch.cuda.ExternalStream(st2.value, device=self.dev)
+
+    def _check_flags(self):
+        """Reads the pinned report word of the device-side waits (no synchronisation).  Raises once per report and clears it,
+        so that close() can still drain and release the streams afterwards."""
+        fe = self._flag_err
+        if fe is None:
+            return
+        code = int(fe[0])
+        if code:
+            fe[0] = 0
+            self._failed = True
+            what = ("is overdue (it is still waiting: nothing ran out of order)" if code == 1
+                    else "gave up: what its stream did afterwards was not ordered against the other stream")
+            raise RuntimeError(f"TrainPipeline: a device-side wait between the extraction and the classifier stream {what} "
+                               f"after {self._flag_timeout_ms} ms without the other stream's signal; LIPASR_GPU_FLAGS=0 uses events")
 
     # ---- pieces (all enqueue on the current stream)
     def _attack_and_train(self, bsz, b, global_batch, defer_dw0=False):
@@ -363,6 +406,7 @@ class TrainPipeline:
         self.feats, self.labels = self._feats2[b], self._labels2[b]
         if self._closed:
             raise RuntimeError("TrainPipeline.step() after close()")
+        self._check_flags()
         # the inputs were produced on the caller's stream (an H2D copy, a noise kernel, a slice of a pool): order the
         # extraction stream after it.  Below, the caller's stream is in turn ordered after this step's extraction, so a
         # temporary handed to step() and freed right after it is not recycled (the caching allocator re-issues a block on
@@ -387,7 +431,7 @@ class TrainPipeline:
             if self._flags is not None:
                 fl = self._flags
                 if self._i > self._nbuf:
-                    N.check(N.lib.lipasr_flag_wait(self.h.h, fl[self._nbuf + b:].data_ptr(), self._i - self._nbuf, self._flag_timeout_ms, fl[2 * self._nbuf:].data_ptr(), N.stream_ptr()))
+                    N.check(N.lib.lipasr_flag_wait(self.h.h, fl[self._nbuf + b:].data_ptr(), self._i - self._nbuf, self._flag_timeout_ms, self._flag_err.data_ptr(), N.stream_ptr()))
             elif self._ev_free[b] is not None:
                 xs.wait_event(self._ev_free[b])  # the step that last read this buffer is done
             if features is not None:
@@ -413,7 +457,7 @@ class TrainPipeline:
         with torch.cuda.stream(self.stream):
             self._warm_start()
             if self._flags is not None:
-                N.check(N.lib.lipasr_flag_wait(self.h.h, self._flags[b:].data_ptr(), self._i, self._flag_timeout_ms, self._flags[2 * self._nbuf:].data_ptr(), N.stream_ptr()))
+                N.check(N.lib.lipasr_flag_wait(self.h.h, self._flags[b:].data_ptr(), self._i, self._flag_timeout_ms, self._flag_err.data_ptr(), N.stream_ptr()))
             else:
                 self.stream.wait_event(self._ev_feat[b])
             prof = None
@@ -474,14 +518,12 @@ class TrainPipeline:
             self._wide_stream.synchronize()
         self.mfcc_stream.synchronize()
         self.stream.synchronize()
-        if getattr(self, "_flags", None) is not None and int(self._flags[-1].item()):
-            raise RuntimeError(f"TrainPipeline: a device-side wait between the extraction and the classifier stream gave up after {self._flag_timeout_ms} ms "
-                               "(the other stream never signalled); results since then are not ordered")
+        self._check_flags()
 
     @property
     def mfcc_stream_kind(self):
         """"masked" (its own hardware queue, confined to ``mfcc_cus`` CUs) or "shared" (a pool stream on every CU)."""
-        return "masked" if getattr(self, "_masked_stream", None) is not None else "shared"
+        return "masked" if self._masked_stream is not None else "shared"
 
     def close(self):
         """Drains both streams, destroys this pipeline's graph executables and gives the CU-masked stream (a hardware
@@ -499,26 +541,32 @@ class TrainPipeline:
             # the ExternalStream wrappers point at destroyed queues: nothing may synchronise on them any more
             self.stream = self.mfcc_stream = torch.cuda.current_stream(self.dev)
             return
-        self.synchronize()
+        pending = None
+        try:
+            self.synchronize()
+        except RuntimeError as e:  # a device-side wait reported: finish the teardown (queues, graphs), then tell the caller
+            pending = e
         for g in self._graphs.values():
             for gid in g:
                 N.lib.lipasr_graph_destroy(self.h.h, gid)
         self._graphs.clear()
-        st = getattr(self, "_masked_stream", None)
+        st = self._masked_stream
         if st is not None:
             self._masked_stream = None
             self.mfcc_stream = torch.cuda.Stream(device=self.dev)
             N.lib.lipasr_stream_destroy(self.h.h, st)
-        st = getattr(self, "_masked_train_stream", None)
+        st = self._masked_train_stream
         if st is not None:
             self._masked_train_stream = None
             self.stream = torch.cuda.Stream(device=self.dev)
             N.lib.lipasr_stream_destroy(self.h.h, st)
-        if getattr(self, "_gemm_tiles_set", False) and getattr(self.model, "_plan", None):
+        if self._gemm_tiles_set and getattr(self.model, "_plan", None):
             self._gemm_tiles_set = False
             N.lib.lipasr_mlp_set_gemm_tiles(self.model._plan, 0)  # back to the library's default threshold
         if not self._custom_ex:
             self.ex.close()  # the pipeline's own MFCC plan
+        if pending is not None:
+            raise pending
 
     def __del__(self):
         try:

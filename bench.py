@@ -8,9 +8,12 @@
 One step = one pass of the hot path over one batch of synthetic 1 s @ 16 kHz clips that are already
 resident in HBM:  waveform -> K1 MFCC (+ fused standardisation) -> K2 fwd/bwd (fp32 MFMA) -> [RCCL
 all-reduce of the flat gradient, N > 1] -> K5 Adam + NonNeg -> K3 simple_norm_constraint(rho = 0.1)
-(BASELINE configs 3 and 4; --pgd K adds config 5's PGD-K inner loop).  Per-GPU batch is fixed
-(weak scaling): 1024 clips = config 4's 8192/8 shard; rank 0 additionally times the reference's own
-batch of 512 at N = 1 and reports it under "reference_batch_512".
+(BASELINE configs 3 and 4; --pgd K adds config 5's PGD-K inner loop).  Default: per-GPU batch fixed
+(weak scaling): 1024 clips = config 4's 8192/8 shard.  `--scaling strong` fixes the GLOBAL batch instead
+(`--global-batch`, default 8192 = config 4's) and gives every rank 8192 / N clips per step: the form
+north_star's ">= 6.5x strong scaling at 8 GPUs" is worded in; its N = 1 denominator (one GPU, batch
+8192) is also in every default N = 1 line as "reference_global_batch_8192_1gpu".  Rank 0 additionally
+times the reference's own batch of 512 at N = 1 ("reference_batch_512").
 
 Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events on the stream the kernels run
 on (lipasr_mfcc_profile_*), `cpu_baseline` times the oracle (a NumPy restatement of the reference path;
@@ -346,7 +349,7 @@ def _short(opt_over, pool, batch, device, steps, warmup):
     opt = {"constraint": "product", "pgd": 0, "pgd_eps": 0.5, "bf16": False, "pre_extracted": False, "graph": "auto", "int16": False}
     opt.update(opt_over)
     try:
-        sub = (pool[0][:16 * batch], pool[1][:16 * batch])
+        sub = (pool[0][:16 * batch], pool[1][:16 * batch])  # (a pool shorter than 16 batches is used whole)
         dt, ex = run_config(opt, sub, batch, 0, 1, device, steps, warmup, profile=True)
     except Exception as e:  # the headline must not die with a secondary record
         return {"error": f"{type(e).__name__}: {e}"[:200]}
@@ -390,6 +393,9 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch-per-gpu", type=int, default=1024)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="weak: --batch-per-gpu clips per rank and step (default); strong: "
+                    "--global-batch clips per step over ALL ranks, each rank takes global/N (north_star's 8-GPU bar is worded as strong scaling)")
+    ap.add_argument("--global-batch", type=int, default=8192, help="--scaling strong: clips per step over all ranks (BASELINE config 4: 8192)")
     ap.add_argument("--pool-clips", type=int, default=POOL_CLIPS, help="resident waveform pool per GPU (SURVEY 8d: >= 65536)")
     ap.add_argument("--constraint", default="product", choices=["product", "per_layer", "none"])
     ap.add_argument("--pgd", type=int, default=0, help="PGD iterations per batch (config 5 uses 20)")
@@ -419,19 +425,26 @@ def main():
         import torch.distributed as dist
 
         rank, world = init_from_env("gloo")
-        dt, ex = run_config_dry(min(args.batch_per_gpu, 64), rank, world, args.steps, args.warmup)
+        if args.scaling == "strong":  # the global batch is fixed (scaled down for the CPU stand-in), every rank takes its share
+            gb = min(args.global_batch, 128)
+            if gb % world:
+                raise SystemExit(f"--scaling strong: global batch {gb} is not a multiple of {world} ranks")
+            b_rank = gb // world
+        else:
+            b_rank = min(args.batch_per_gpu, 64)
+            gb = b_rank * world
+        dt, ex = run_config_dry(b_rank, rank, world, args.steps, args.warmup)
         t = torch.tensor([dt], dtype=torch.float64)
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         if rank == 0:
-            gb = min(args.batch_per_gpu, 64) * world
             print(json.dumps({"dry_run": True, "metric": "utterances/sec (DRY RUN: CPU stand-in replica over gloo, not a measurement)",
                               "value": round(gb * args.steps / float(t.item()), 1), "unit": "utterances/sec", "n_gpus": world, "steps": args.steps,
-                              "warmup": args.warmup, "ms_per_step": round(float(t.item()) / args.steps * 1e3, 4), "scaling": "weak",
+                              "warmup": args.warmup, "ms_per_step": round(float(t.item()) / args.steps * 1e3, 4), "scaling": args.scaling,
                               "rccl_ranks_seen": ex["comm"]["ranks_seen"], "rccl_version": ex["comm"]["rccl_version"], "comm_backend": ex["comm"]["backend"],
                               "allreduce_ms": round(ex["allreduce_ms"], 4) if ex["allreduce_ms"] is not None else None,
                               "replica_divergence": ex["divergence"], "loss": round(ex["loss"], 4),
-                              "config": {"global_batch": gb, "parallelism": f"dp{world}"}}), flush=True)
+                              "config": {"global_batch": gb, "per_gpu_batch": b_rank, "parallelism": f"dp{world}"}}), flush=True)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -445,6 +458,10 @@ def main():
         print(json.dumps(run_fit_api(device)), flush=True)
         return
     batch = args.batch_per_gpu
+    if args.scaling == "strong":
+        if args.global_batch % world or args.global_batch < world:
+            raise SystemExit(f"--scaling strong: global batch {args.global_batch} is not a multiple of {world} ranks")
+        batch = args.global_batch // world
     pool = make_pool(max(args.pool_clips, 8 * batch) // batch * batch, device, seed=1234 + rank)
     dt, ex = run_config(opt, pool, batch, rank, world, device, args.steps, args.warmup, profile=True)
     t = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -516,7 +533,7 @@ def main():
                     "note": "whole step incl. BatchNorm, Adam and projection kernels; GEMM-only time is in profiles/"}
     out = {"metric": "utterances/sec (train, 1 s@16 kHz)", "value": round(value, 1), "unit": "utterances/sec", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
-           "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.bf16 else "f32", "data": "synthetic",
+           "scaling": args.scaling, "vs_baseline": None, "dtype": "bf16" if args.bf16 else "f32", "data": "synthetic",
            "config": {"workload": ("pre-extracted standardised (N,880) MFCC features" if args.pre_extracted else "raw 16 kHz waveform -> on-GPU MFCC")
                                   + " -> Lipschitz-constrained MLP train step (Adam+NonNeg, simple_norm_constraint rho=0.1)" + (f" + PGD-{args.pgd} adversarial inner loop" if args.pgd else "")
                                   + (", data-parallel RCCL gradient all-reduce" if world > 1 else ", 1xMI355X"),
@@ -545,6 +562,11 @@ def main():
     if world == 1 and not args.skip_other_configs and not (args.pgd or args.pre_extracted or args.bf16):
         # the other single-GPU BASELINE configurations, in the driver-run record (short runs; each is its own model + pipeline)
         k, w = min(args.steps, 50), min(args.warmup, 10)
+        if batch != 8192:
+            # north_star's 8-GPU bar is STRONG scaling at global batch 8192: this is its denominator -- the same step with all 8192
+            # clips on one GPU (same pool, same pipeline, its own CU split).  8 x 1024-clip shards in T8 ms against this record's
+            # ms_per_step is the strong-scaling speed-up; `--scaling strong --gpus N` measures the numerator in that form.
+            out["reference_global_batch_8192_1gpu"] = _short({}, pool, 8192, device, min(k, 20), min(w, 5))
         out["reference_config_2_pre_extracted_f32"] = _short({"pre_extracted": True}, pool, batch, device, k, w)
         out["reference_config_2_pre_extracted_bf16"] = _short({"pre_extracted": True, "bf16": True}, pool, batch, device, k, w)
         out["reference_config_5_pgd20_1gpu"] = _short({"pgd": 20, "pgd_eps": 0.5}, pool, batch, device, min(k, 20), min(w, 5))

@@ -8,6 +8,10 @@
  * "/root/reference/Voice digit recogniton/") whose arithmetic it replaces.
  * INTEGRATION.md shows the ctypes binding a maintainer would add.
  *
+ * lipasr_version(): 500 = round 5.  ABI history: 300 (round 3) -> round 4 added lipasr_flag_signal / lipasr_flag_wait and
+ * lipasr_debug_chain_head without a bump -> 500: lipasr_flag_wait reports and keeps waiting (see its comment), plus the
+ * round-5 entry points marked "(round 5)" below.
+ *
  * Conventions
  *   - every function returns int: 0 = LIPASR_OK, negative = LIPASR_E*; nothing
  *     throws across the ABI; lipasr_last_error() returns a thread-local message.
@@ -69,9 +73,13 @@ int lipasr_timer_elapsed_ms(lipasr_handle_t h, int timer_id, float* ms_host);
 
 /* Device-side ordering between two streams: `flag` is an int in device memory (start at 0, raise monotonically).
  * lipasr_flag_signal stores `value` when the stream reaches it; lipasr_flag_wait holds its stream until *flag >= value (a
- * one-wavefront kernel that polls; after timeout_ms it sets *err = 1, a device int, and lets the stream go on: a missing signal
- * is an error code, never a hung queue).  Cheaper on the waiting stream than hipEventRecord + hipStreamWaitEvent.  The two
- * streams must be able to run concurrently (e.g. disjoint CU masks, or spare wave slots: the waiting wavefront holds one). */
+ * one-wavefront kernel that polls).  After timeout_ms it REPORTS (*err = 1) and keeps waiting: the ordering is never given up
+ * because a peer was slow (round 4 let the stream go on there).  After 4 x timeout_ms it gives up (*err = 2) so that a signal
+ * that can never come drains the queue instead of hanging it; a wait that finds *err == 2 when its own timeout passes leaves at
+ * once.  `err` is an int the kernel writes with system scope: device memory, or pinned host memory the caller reads without
+ * synchronising (what lipasr/pipeline.py does at the top of every step).  Cheaper on the waiting stream than hipEventRecord +
+ * hipStreamWaitEvent.  The two streams must be able to run concurrently (e.g. disjoint CU masks, or spare wave slots: the
+ * waiting wavefront holds one); under a tool that serialises kernels across streams (rocprofv3 --pmc) use events. */
 int lipasr_flag_signal(lipasr_handle_t h, int* flag, int value, lipasr_stream_t stream);
 int lipasr_flag_wait(lipasr_handle_t h, const int* flag, int value, int timeout_ms, int* err, lipasr_stream_t stream);
 

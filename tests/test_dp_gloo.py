@@ -246,22 +246,27 @@ def test_batchnorm_and_dropout_under_data_parallel(tmp_path):
     assert abs(r0["acc"] - acc1) <= 0.005 and abs(r1["acc"] - acc1) <= 0.005, (acc1, r0["acc"], r1["acc"])
 
 
-def test_bench_dry_run_dp_under_torchrun():
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_dry_run_dp_under_torchrun(scaling):
     """bench.py --dry-run-dp under torch.distributed.run with two ranks: the script's own world > 1 flow
     -- env rendezvous on 127.0.0.1, communicator probe (SUM of ones = ranks the backend really reduced over), broadcast of
     the scaler and the start state from rank 0 to replicas that start DIFFERENT, shard -> all-reduce -> update steps, barrier
-    + MAX-over-ranks timing, one JSON line from rank 0 with the data-parallel fields."""
+    + MAX-over-ranks timing, one JSON line from rank 0 with the data-parallel fields.  Round 5: in both
+    scaling modes -- weak (per-rank batch fixed, the default) and strong (`--scaling strong`: the GLOBAL batch fixed, each rank
+    takes global / N; the form north_star's 8-GPU bar is worded in)."""
     import json
     import subprocess
 
     port = _free_port() if "_free_port" in globals() else 29533
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--dry-run-dp"]
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--dry-run-dp", "--scaling", scaling]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1  # rank 0 only
     d = json.loads(lines[0])
     assert d["dry_run"] is True and d["n_gpus"] == 2 and d["rccl_ranks_seen"] == 2 and d["comm_backend"] == "gloo"
-    assert d["replica_divergence"] == 0.0 and d["allreduce_ms"] > 0 and d["config"]["global_batch"] == 128
+    assert d["scaling"] == scaling
+    # weak: 64 per rank -> 128 global; strong: the global batch (8192, scaled down to 128 for the CPU stand-in) split 64 | 64
+    assert d["replica_divergence"] == 0.0 and d["allreduce_ms"] > 0 and d["config"]["global_batch"] == 128 and d["config"]["per_gpu_batch"] == 64
     assert np.isfinite(d["loss"]) and d["value"] > 0
