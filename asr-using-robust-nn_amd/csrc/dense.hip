@@ -30,7 +30,10 @@ enum Epi {
   EPI_BIAS_RELU_STATS = 6,  // training forward: a = relu(acc + b) and per-tile column sums of a, a^2
   EPI_DH_STATS = 7,         // training backward: g = acc * dropout and per-tile column sums of g, g * xhat
   EPI_DZ_NOBN = 8,          // training backward through Dropout -> ReLU without BatchNorm
-  EPI_BIAS_SOFTMAX_CE = 9   // last layer (N <= 32, one column tile): logits, softmax, CE loss and (p - y) / B in one
+  EPI_BIAS_SOFTMAX_CE = 9,  // last layer (N <= 32, one column tile): logits, softmax, CE loss and (p - y) / B in one
+  EPI_BIAS_RELU_BNX = 10,   // round 5, training forward: a = relu(acc + b), BatchNorm statistics exchanged between the row tiles of
+                            // the column block inside the launch, h = dropout(BN(a)) -- no apply kernel
+  EPI_DH_BNX = 11           // round 5, training backward: g = acc * dropout, sums of g, g xhat exchanged, dz = BN/ReLU backward
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -86,6 +89,19 @@ struct GemmArgs {
   // (v_mfma_f32_32x32x16_bf16): BASELINE config 2's arithmetic; memory stays fp32.
   int bf16;
   int lds_min_tiles;  // host side only: 64x64 tiles from which launch_gemm takes the LDS-tiled kernel (0 = the default)
+  // EPI_BIAS_RELU_BNX / EPI_DH_BNX (the exchange epilogue)
+  unsigned long long* xc_gran;  // [32-column block][xc_rt_max][128] {tag, value}
+  unsigned* xc_ctrl;            // [32-column block][32]: word 0 generation, word 1 arrivals
+  int* xc_err;
+  int xc_rt_max;
+  int Bstat;                    // rows the statistics are taken over
+  float grad_scale;             // EPI_DH_BNX: factor on dgamma / dbeta
+  float* h_out;                 // EPI_BIAS_RELU_BNX: BatchNorm + dropout output (C receives the post-ReLU activations)
+  float* mmean_w;               // EPI_BIAS_RELU_BNX: moving statistics (updated by row tile 0), saved batch mean | rstd
+  float* mvar_w;
+  float* save_w;
+  float* dgamma;                // EPI_DH_BNX
+  float* dbeta;
 };
 
 // eight consecutive-k fp32 operand values of a lane -> one bf16 fragment (lane (r, h) holds k = 8 h + j, j < 8)
@@ -170,10 +186,192 @@ __device__ __forceinline__ float epilogue_elem(const GemmArgs& g, int step, int 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Round 5: the exchange epilogue.  Training-mode BatchNorm needs column statistics over ALL rows of the batch, i.e. over
+// every row tile of a column block; until round 4 the GEMM left per-tile partial sums and a second kernel (bn_apply_*) summed
+// them and transformed the tile -- a launch boundary plus a cold round trip for the activations it had just written
+// (8.4 / 5.9 us per layer and direction, 72 us of a 352 us step).  Here the row tiles of one column block exchange their
+// partial sums inside the launch and every tile finishes its own BatchNorm on the values it still holds in registers:
+//   * each tile publishes its 2 x CB partial sums as 8-byte {tag, value} granules (one sc1 store each: the data is the flag),
+//   * sweeps the granules of the block's other row tiles until every tag equals this launch's tag (relaxed sc1 loads; the
+//     sums are then added in a fixed order in fp64: bitwise reproducible, no float atomics),
+//   * and arrives on the block's counter; the last arriver resets it and advances the block's generation, so the next launch
+//     (ordered behind this one by the stream) uses the next tag.  Every workgroup reads the generation before it publishes,
+//     and the generation cannot move before every workgroup of the block has arrived: all of them use the same tag.
+// Needs every workgroup of a column block resident at the same time: the host takes this path only when the whole grid fits
+// the CUs the plan's stream may use (bnx_fits), and the sweep is bounded by a wall-clock limit that sets an error word and
+// lets the grid drain.  scratch/link_bench.hip (c) prices the exchange alone: 3.7 us (16 row tiles) to 5.5-6.9 us (32).
+// ---------------------------------------------------------------------------------------------
+struct XcView {
+  unsigned long long* gran;
+  unsigned* ctrl;
+  int* err;
+  int rt_max;
+};
+constexpr long long kXcTimeoutTicks = 200000000LL;  // 2 s of the 100 MHz wall clock
+
+// NT threads; CB columns per block (32: the fragment kernel, 64: the LDS-tiled kernel).  mine[2 CB]: this tile's partial sums
+// (LDS).  On return tot[2 CB] (LDS, fp64) holds the sums over all n_rt row tiles.  sbuf: LDS, (NT / (2 CB)) x 2 CB doubles.
+template <int NT, int CB>
+__device__ __forceinline__ void xc_exchange(const XcView& xc, int bx, int by, int n_rt, const float* mine, double* sbuf, double* tot) {
+  constexpr int NI = 2 * CB, PER = NT / NI, MAXK = 64 / PER;
+  typedef unsigned long long u64;
+  const int tid = threadIdx.x, item = tid % NI, rl = tid / NI;
+  const int jblk = bx * (CB / 32);
+  unsigned* cw = xc.ctrl + (size_t)jblk * 32;
+  u64* g = xc.gran + (size_t)jblk * xc.rt_max * 128;
+  const unsigned want = __hip_atomic_load(cw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+  if (tid < NI)
+    __hip_atomic_store(g + (size_t)by * 128 + tid, ((u64)want << 32) | (u64)__float_as_uint(mine[tid]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  float v[MAXK];
+  const long long t0 = wall_clock64();
+  for (;;) {
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) {
+      const int t = rl + PER * k;
+      v[k] = 0.0f;
+      if (t < n_rt) {
+        const u64 x = __hip_atomic_load(g + (size_t)t * 128 + item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = ok && (unsigned)(x >> 32) == want;
+        v[k] = __uint_as_float((unsigned)x);
+      }
+    }
+    if (__syncthreads_and(ok)) break;
+    if (__syncthreads_or(wall_clock64() - t0 > kXcTimeoutTicks)) {  // (uniform: every thread leaves or none)
+      if (tid == 0) __hip_atomic_store(xc.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
+    }
+    __builtin_amdgcn_s_sleep(4);
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < MAXK; ++k) s += (double)v[k];  // (slots past n_rt hold 0)
+  sbuf[rl * NI + item] = s;
+  __syncthreads();
+  if (tid < NI) {
+    double t = 0.0;
+#pragma unroll
+    for (int r = 0; r < PER; ++r) t += sbuf[r * NI + tid];
+    tot[tid] = t;
+  }
+  if (tid == 0) {
+    const unsigned old = __hip_atomic_fetch_add(cw + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == (unsigned)n_rt - 1u) {  // the last row tile of the block: nobody reads the generation any more in this launch
+      __hip_atomic_store(cw + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(cw, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  __syncthreads();
+}
+
+// BatchNorm element arithmetic shared by the apply kernels and the exchange epilogues
+__device__ __forceinline__ void bn_col_stats(double s1, double s2, int Bstat, float& mean, float& var, float& rstd) {
+  const double m = s1 / (double)Bstat;
+  double v = s2 / (double)Bstat - m * m;
+  v = v > 0.0 ? v : 0.0;
+  mean = (float)m;
+  var = (float)v;
+  rstd = (float)(1.0 / sqrt(v + (double)kBnEps));
+}
+
+// The tile's R rows x 4 columns per thread after the exchange.  val: a (forward) or g (backward); av: post-ReLU a (backward).
+// colp (LDS floats): forward [mean | rstd] per column of the block, backward [dbeta | dgamma].
+template <int R>
+__device__ __forceinline__ void bnx_finish(const GemmArgs& g, const int step, const int* gm, const int gn, const float (*val)[4],
+                                           const float (*av)[4], const float* colp, const int CB, const int c4) {
+  const bool fwd = g.epi == EPI_BIAS_RELU_BNX;
+  float ga[4], p0[4], p1[4], be[4], mean[4], rstd[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const bool cv = gn + e < g.N;
+    ga[e] = cv ? g.gamma[gn + e] : 1.0f;
+    p0[e] = colp[c4 + e];
+    p1[e] = colp[CB + c4 + e];
+    if (fwd) {
+      be[e] = cv ? g.beta[gn + e] : 0.0f;
+      mean[e] = p0[e]; rstd[e] = p1[e];
+    } else {
+      be[e] = 0.0f;
+      mean[e] = cv ? g.save_mean[gn + e] : 0.0f;
+      rstd[e] = cv ? g.save_mean[g.N + gn + e] : 1.0f;
+    }
+  }
+  const float invB = 1.0f / (float)g.Bstat;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (gm[r] >= g.M) continue;
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const size_t idx = (size_t)gm[r] * g.ldc + gn + e;
+      if (fwd) {
+        float x = (val[r][e] - mean[e]) * rstd[e] * ga[e] + be[e];
+        x *= (gn + e < g.N) ? dropout_mult(g.drop, step, idx) : 0.0f;
+        o[e] = x;
+      } else {
+        const float xh = (av[r][e] - mean[e]) * rstd[e];
+        const float d = ga[e] * rstd[e] * (val[r][e] - p0[e] * invB - xh * p1[e] * invB);
+        o[e] = av[r][e] > 0.0f ? d : 0.0f;
+      }
+    }
+    float* crow = (fwd ? g.h_out : g.C) + (size_t)gm[r] * g.ldc;
+    if (gn + 3 < g.N && ((g.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(crow) & 15) == 0)) {
+      *reinterpret_cast<float4*>(crow + gn) = make_float4(o[0], o[1], o[2], o[3]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (gn + e < g.N) crow[gn + e] = o[e];
+    }
+  }
+}
+
+// one column of the block after the exchange: forward -> [mean | rstd] (+ moving statistics and the saved statistics, by
+// row tile 0), backward -> [dbeta | dgamma] (+ the parameter gradients, by row tile 0)
+__device__ __forceinline__ void bnx_column(const GemmArgs& g, const int by, const int col, const int j, const int CB, const double* tot,
+                                           float* colp) {
+  if (g.epi == EPI_BIAS_RELU_BNX) {
+    float mean, var, rstd;
+    bn_col_stats(tot[j], tot[CB + j], g.Bstat, mean, var, rstd);
+    colp[j] = mean;
+    colp[CB + j] = rstd;
+    if (by == 0 && col < g.N) {
+      g.mmean_w[col] = g.mmean_w[col] * kBnMomentum + mean * (1.0f - kBnMomentum);
+      g.mvar_w[col] = g.mvar_w[col] * kBnMomentum + var * (1.0f - kBnMomentum);
+      g.save_w[col] = mean;
+      g.save_w[g.N + col] = rstd;
+    }
+  } else {
+    const float dbt = (float)tot[j], dg = (float)tot[CB + j];
+    colp[j] = dbt;
+    colp[CB + j] = dg;
+    if (by == 0 && col < g.N) {
+      g.dbeta[col] = dbt * g.grad_scale;
+      g.dgamma[col] = dg * g.grad_scale;
+    }
+  }
+}
+
+// the element before the exchange: value kept in registers, its two statistics; forward also stores a
+__device__ __forceinline__ void bnx_elem(const GemmArgs& g, const int step, const bool cv, const int gm, const int gn, const float acc,
+                                         float& val, float& av, float& s1, float& s2) {
+  if (g.epi == EPI_BIAS_RELU_BNX) {
+    const float a = cv ? fmaxf(acc + g.bias[gn], 0.0f) : 0.0f;
+    val = a; av = a; s1 = a; s2 = a * a;
+  } else {
+    const size_t idx = (size_t)gm * g.ldc + gn;
+    const float gg = cv ? acc * dropout_mult(g.drop, step, idx) : 0.0f;
+    const float a = cv ? g.aux[idx] : 0.0f;
+    const float xh = cv ? (a - g.save_mean[gn]) * g.save_mean[g.N + gn] : 0.0f;
+    val = gg; av = a; s1 = gg; s2 = gg * xh;
+  }
+}
+
 // One workgroup = one 32x32 output tile; its NW wavefronts (4, or 16 for small outputs with a long K) split K
 // in 16-deep chunks, round-robin.  Operand fragments go global/L2 -> VGPR directly, one chunk ahead of the MFMAs.
-template <int AMODE, int BMODE, int NW, bool BF>
-__device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const int by, const int n_row_tiles) {
+template <int AMODE, int BMODE, int NW, bool BF, bool X = false>  // X: the exchange epilogue (its own instances: with it as a run-time
+__device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const int by, const int n_row_tiles) {  // branch every GEMM grew from 50-66 to 83 VGPRs)
   constexpr int TS = 32;
   constexpr int TPR = 8;                       // threads per output row (one float4 each)
   extern __shared__ __attribute__((aligned(16))) float red[];  // [NW][32][32] + stats [4][8][8]
@@ -226,6 +424,68 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
     red[wave * TS * TS + row * TS + r] = acc[q];
   }
   __syncthreads();
+
+  if constexpr (X && NW == 4) {
+    {
+      const int step = g.drop.step_dev ? *g.drop.step_dev : 0;
+      const int tcol = tid & 7, row = tid >> 3, c4 = tcol * 4, gn = n0 + c4;
+      const int gm1[1] = {m0 + row};
+      float4 s = *reinterpret_cast<const float4*>(red + row * TS + c4);
+#pragma unroll
+      for (int w = 1; w < NW; ++w) {
+        const float4 t = *reinterpret_cast<const float4*>(red + w * TS * TS + row * TS + c4);
+        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+      }
+      const float accv[4] = {s.x, s.y, s.z, s.w};
+      float val[1][4], av[1][4], c1[4], c2[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bnx_elem(g, step, gm1[0] < g.M && gn + e < g.N, gm1[0], gn + e, accv[e], val[0][e], av[0][e], c1[e], c2[e]);
+      if (g.epi == EPI_BIAS_RELU_BNX && gm1[0] < g.M) {  // the post-ReLU activations: the backward pass reads them
+        float* crow = g.C + (size_t)gm1[0] * g.ldc;
+        if (gn + 3 < g.N && ((g.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(crow) & 15) == 0)) {
+          *reinterpret_cast<float4*>(crow + gn) = make_float4(val[0][0], val[0][1], val[0][2], val[0][3]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (gn + e < g.N) crow[gn + e] = val[0][e];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int o = TPR; o < 64; o <<= 1) {
+          c1[e] += __shfl_xor(c1[e], o, 64);
+          c2[e] += __shfl_xor(c2[e], o, 64);
+        }
+      }
+      if (lane < TPR) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          stat[(wave * TPR + lane) * 8 + e] = c1[e];
+          stat[(wave * TPR + lane) * 8 + 4 + e] = c2[e];
+        }
+      }
+      __syncthreads();  // (also: every read of `red` is done, it is carved up below)
+      float* mine = red;                                       // [2][32]
+      float* colp = red + 64;                                  // [2][32]
+      double* sbuf = reinterpret_cast<double*>(red + 128);     // [4][64]
+      double* tot = sbuf + 4 * 64;                             // [64]
+      if (tid < 2 * TS) {
+        const int which = tid / TS, col = tid % TS, l4 = col >> 2, e = col & 3;
+        float t = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) t += stat[(w * TPR + l4) * 8 + which * 4 + e];
+        mine[tid] = t;
+      }
+      __syncthreads();
+      XcView xc{g.xc_gran, g.xc_ctrl, g.xc_err, g.xc_rt_max};
+      xc_exchange<256, 32>(xc, bx, by, n_row_tiles, mine, sbuf, tot);
+      if (tid < TS) bnx_column(g, by, n0 + tid, tid, TS, tot, colp);
+      __syncthreads();
+      bnx_finish<1>(g, step, gm1, gn, val, av, colp, TS, c4);
+      return;
+    }
+  }
 
   const bool stats = (g.epi == EPI_BIAS_RELU_STATS) || (g.epi == EPI_DH_STATS);
   float cs1[4] = {0.f, 0.f, 0.f, 0.f}, cs2[4] = {0.f, 0.f, 0.f, 0.f};
@@ -348,9 +608,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
   }
 }
 
-template <int AMODE, int BMODE, int NW, bool BF = false>  // BF: operands rounded to bf16 at the MFMA (compile-time: a
+template <int AMODE, int BMODE, int NW, bool BF = false, bool X = false>  // BF: operands rounded to bf16 at the MFMA (compile-time: a
 __global__ __launch_bounds__(64 * NW) void gemm_f32_kernel(GemmArgs g) {  // run-time switch cost the fp32 path 6 %)
-  gemm_tile<AMODE, BMODE, NW, BF>(g, blockIdx.x, blockIdx.y, gridDim.y);
+  gemm_tile<AMODE, BMODE, NW, BF, X>(g, blockIdx.x, blockIdx.y, gridDim.y);
 }
 
 // Several independent GEMMs of one (AMODE, BMODE) in ONE launch: the six weight-gradient GEMMs of a training step
@@ -439,7 +699,7 @@ constexpr size_t lds_gemm_bytes(int bk) {
   return ((size_t)(2 * 2 * bk * kLdsLD > 2 * 64 * 64 ? 2 * 2 * bk * kLdsLD : 2 * 64 * 64) + 8 * 16 * 8) * sizeof(float);
 }
 
-template <int AMODE, int BMODE, bool BF, int BK>  // BK: k rows per LDS tile (32 or 64)
+template <int AMODE, int BMODE, bool BF, int BK, bool X = false>  // BK: k rows per LDS tile (32 or 64); X: the exchange epilogue
 __device__ __forceinline__ void gemm_lds_tile(const GemmArgs& g, const int bx, const int by, const int n_row_tiles) {
   constexpr int TS = 64;
   constexpr int NF = BK / kLdsBK;  // 32-row fetches per operand and tile
@@ -525,6 +785,65 @@ __device__ __forceinline__ void gemm_lds_tile(const GemmArgs& g, const int bx, c
   const int step = g.drop.step_dev ? *g.drop.step_dev : 0;
   const int tcol = tid & 15, trow = tid >> 4;
   const int c4 = tcol * 4, gn = n0 + c4;
+  if constexpr (X) {
+    const int gm2[2] = {m0 + trow, m0 + trow + 32};
+    float val[2][4], av[2][4], c1[4] = {0.f, 0.f, 0.f, 0.f}, c2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int row = trow + 32 * pass;
+      float4 s = *reinterpret_cast<const float4*>(red + row * TS + c4);
+      const float4 s2 = *reinterpret_cast<const float4*>(red + TS * TS + row * TS + c4);
+      const float accv[4] = {s.x + s2.x, s.y + s2.y, s.z + s2.z, s.w + s2.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float t1, t2;
+        bnx_elem(g, step, gm2[pass] < g.M && gn + e < g.N, gm2[pass], gn + e, accv[e], val[pass][e], av[pass][e], t1, t2);
+        c1[e] += t1;
+        c2[e] += t2;
+      }
+      if (g.epi == EPI_BIAS_RELU_BNX && gm2[pass] < g.M) {
+        float* crow = g.C + (size_t)gm2[pass] * g.ldc;
+        if (gn + 3 < g.N && ((g.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(crow) & 15) == 0)) {
+          *reinterpret_cast<float4*>(crow + gn) = make_float4(val[pass][0], val[pass][1], val[pass][2], val[pass][3]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (gn + e < g.N) crow[gn + e] = val[pass][e];
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      c1[e] += __shfl_xor(c1[e], 16, 64); c1[e] += __shfl_xor(c1[e], 32, 64);
+      c2[e] += __shfl_xor(c2[e], 16, 64); c2[e] += __shfl_xor(c2[e], 32, 64);
+    }
+    if (lane < 16) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        stat[(wave * 16 + lane) * 8 + e] = c1[e];
+        stat[(wave * 16 + lane) * 8 + 4 + e] = c2[e];
+      }
+    }
+    __syncthreads();  // (every read of `red` is done: it is carved up below)
+    float* mine = red;                                       // [2][64]
+    float* colp = red + 128;                                 // [2][64]
+    double* sbuf = reinterpret_cast<double*>(red + 256);     // [4][128]
+    double* tot = sbuf + 4 * 128;                            // [128]
+    if (tid < 2 * TS) {
+      const int which = tid / TS, col = tid % TS, l4 = col >> 2, e = col & 3;
+      float t = 0.0f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) t += stat[(w * 16 + l4) * 8 + which * 4 + e];
+      mine[tid] = t;
+    }
+    __syncthreads();
+    XcView xc{g.xc_gran, g.xc_ctrl, g.xc_err, g.xc_rt_max};
+    xc_exchange<512, 64>(xc, bx, by, n_row_tiles, mine, sbuf, tot);
+    if (tid < TS) bnx_column(g, by, n0 + tid, tid, TS, tot, colp);
+    __syncthreads();
+    bnx_finish<2>(g, step, gm2, gn, val, av, colp, TS, c4);
+    return;
+  }
   float cs1[4] = {0.f, 0.f, 0.f, 0.f}, cs2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
@@ -580,9 +899,9 @@ __device__ __forceinline__ void gemm_lds_tile(const GemmArgs& g, const int bx, c
   }
 }
 
-template <int AMODE, int BMODE, bool BF = false, int BK = kLdsBKMax>
+template <int AMODE, int BMODE, bool BF = false, int BK = kLdsBKMax, bool X = false>
 __global__ __launch_bounds__(512) void gemm_lds_kernel(GemmArgs g) {
-  gemm_lds_tile<AMODE, BMODE, BF, BK>(g, blockIdx.x, blockIdx.y, gridDim.y);
+  gemm_lds_tile<AMODE, BMODE, BF, BK, X>(g, blockIdx.x, blockIdx.y, gridDim.y);
 }
 
 // The grouped launch with 64x64 LDS tiles: the weight-gradient GEMMs read both operands k-major (lin[k][i], dz[k][j]), which
@@ -691,6 +1010,40 @@ static int launch_gemm(int amode, int bmode, const GemmArgs& g, hipStream_t st) 
     LP_LAUNCH_CHECK();
     return LIPASR_OK;
   }
+  if (g.epi == EPI_BIAS_RELU_BNX || g.epi == EPI_DH_BNX) {  // the exchange epilogue: forward (NN) or input-gradient (NT) GEMMs only
+    if (amode != 0) { set_error("gemm: the exchange epilogue needs a row-major A operand"); return LIPASR_EINVAL; }
+    if (use_lds_gemm(g.M, g.N, g.K, g.lds_min_tiles)) {
+      const dim3 grid((g.N + 63) / 64, (g.M + 63) / 64);
+      constexpr size_t lds_b = lds_gemm_bytes(kLdsBKMax);
+      static bool attr_set_dev[16] = {}; int attr_dev = 0; (void)hipGetDevice(&attr_dev); bool& attr_set = attr_set_dev[attr_dev & 15];
+      if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_lds_kernel<0, 0, false, kLdsBKMax, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_lds_kernel<0, 0, true, kLdsBKMax, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_lds_kernel<0, 1, false, kLdsBKMax, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_lds_kernel<0, 1, true, kLdsBKMax, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
+        attr_set = true;
+      }
+      if (bmode == 0) {
+        if (g.bf16) hipLaunchKernelGGL((gemm_lds_kernel<0, 0, true, kLdsBKMax, true>), grid, dim3(512), lds_b, st, g);
+        else hipLaunchKernelGGL((gemm_lds_kernel<0, 0, false, kLdsBKMax, true>), grid, dim3(512), lds_b, st, g);
+      } else {
+        if (g.bf16) hipLaunchKernelGGL((gemm_lds_kernel<0, 1, true, kLdsBKMax, true>), grid, dim3(512), lds_b, st, g);
+        else hipLaunchKernelGGL((gemm_lds_kernel<0, 1, false, kLdsBKMax, true>), grid, dim3(512), lds_b, st, g);
+      }
+    } else {
+      const dim3 grid((g.N + 31) / 32, (g.M + 31) / 32);
+      const size_t lds = (size_t)(4 * 32 * 32 + 4 * 8 * 8) * sizeof(float);
+      if (bmode == 0) {
+        if (g.bf16) hipLaunchKernelGGL((gemm_f32_kernel<0, 0, 4, true, true>), grid, dim3(256), lds, st, g);
+        else hipLaunchKernelGGL((gemm_f32_kernel<0, 0, 4, false, true>), grid, dim3(256), lds, st, g);
+      } else {
+        if (g.bf16) hipLaunchKernelGGL((gemm_f32_kernel<0, 1, 4, true, true>), grid, dim3(256), lds, st, g);
+        else hipLaunchKernelGGL((gemm_f32_kernel<0, 1, 4, false, true>), grid, dim3(256), lds, st, g);
+      }
+    }
+    LP_LAUNCH_CHECK();
+    return LIPASR_OK;
+  }
   if (use_lds_gemm(g.M, g.N, g.K, g.lds_min_tiles)) {
     const dim3 grid((g.N + 63) / 64, (g.M + 63) / 64);
     constexpr size_t lds_b = lds_gemm_bytes(kLdsBKMax);
@@ -714,7 +1067,8 @@ static int launch_gemm(int amode, int bmode, const GemmArgs& g, hipStream_t st) 
     return LIPASR_OK;
   }
   const long tiles = (long)((g.N + 31) / 32) * ((g.M + 31) / 32);
-  const bool deep = tiles <= 192 && g.K >= 512 && g.epi != EPI_BIAS_RELU_STATS && g.epi != EPI_DH_STATS;
+  const bool deep = tiles <= 192 && g.K >= 512 && g.epi != EPI_BIAS_RELU_STATS && g.epi != EPI_DH_STATS && g.epi != EPI_BIAS_RELU_BNX &&
+                    g.epi != EPI_DH_BNX;
   if (deep) {
     if (amode == 0 && bmode == 0) launch_gemm_t<0, 0, 16>(g, st);
     else if (amode == 0 && bmode == 1) launch_gemm_t<0, 1, 16>(g, st);
@@ -732,6 +1086,47 @@ static int launch_gemm(int amode, int bmode, const GemmArgs& g, hipStream_t st) 
 
 // row tiles of the *_STATS epilogues: must follow the kernel choice of launch_gemm for the same (M, N, K)
 static int stats_row_tiles(int M, int N, int K, int min_tiles) { return use_lds_gemm(M, N, K, min_tiles) ? (M + 63) / 64 : (M + 31) / 32; }
+
+// The exchange epilogue (EPI_*_BNX) spins until every row tile of its column block has published: every workgroup of the launch
+// must be able to be resident at the same time.  Workgroups per CU = the occupancy query capped by the SGPR admission rule
+// (blocks_per_cu), times the CUs the plan's stream may use.  The row tiles must also fit the
+// granule regions.  Anything else takes the launch chain (GEMM + apply kernel).
+template <typename K>
+static int blocks_per_cu(K kernel, int threads, size_t lds) {
+  int occ = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, threads, lds) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  // MI355X_MICROARCH.md (residency): the hardware admits 256-thread blocks up to floor(800 / (ceil(sgpr / 16) 16 + 16)) per CU,
+  // which the query does not know about (it can be one high).  These kernels use 102-106 SGPRs (GemmArgs is a large by-value
+  // argument): 800 / 128 = 6 blocks of four wavefronts = 24 wavefronts per CU.
+  const int by_sgpr = 24 / (threads / 64);
+  return std::min(occ, by_sgpr);
+}
+
+static bool bnx_fits(const lipasr_mlp* m, bool forward, int M, int N, int K) {
+  if (!m->fuse_bn || !m->xc_gran) return false;
+  const bool lds_k = use_lds_gemm(M, N, K, m->lds_min_tiles);
+  const int ts = lds_k ? 64 : 32;
+  const long row_tiles = (M + ts - 1) / ts, tiles = row_tiles * ((N + ts - 1) / ts);
+  if (row_tiles > m->xc_rt_max || row_tiles > 64) return false;
+  // [forward | backward][fragment | LDS kernel][fp32 | bf16 operands], filled on first use (one device per process in practice;
+  // the kernels' resource use does not depend on the device)
+  static int per_cu[2][2][2] = {{{-1, -1}, {-1, -1}}, {{-1, -1}, {-1, -1}}};
+  int& pc = per_cu[forward ? 0 : 1][lds_k ? 1 : 0][m->compute_bf16 ? 1 : 0];
+  if (pc < 0) {
+    const size_t lds_f = (size_t)(4 * 32 * 32 + 4 * 8 * 8) * sizeof(float);
+    if (forward) {
+      if (lds_k) pc = m->compute_bf16 ? blocks_per_cu(gemm_lds_kernel<0, 1, true, kLdsBKMax, true>, 512, lds_gemm_bytes(kLdsBKMax))
+                                      : blocks_per_cu(gemm_lds_kernel<0, 1, false, kLdsBKMax, true>, 512, lds_gemm_bytes(kLdsBKMax));
+      else pc = m->compute_bf16 ? blocks_per_cu(gemm_f32_kernel<0, 1, 4, true, true>, 256, lds_f) : blocks_per_cu(gemm_f32_kernel<0, 1, 4, false, true>, 256, lds_f);
+    } else {
+      if (lds_k) pc = m->compute_bf16 ? blocks_per_cu(gemm_lds_kernel<0, 0, true, kLdsBKMax, true>, 512, lds_gemm_bytes(kLdsBKMax))
+                                      : blocks_per_cu(gemm_lds_kernel<0, 0, false, kLdsBKMax, true>, 512, lds_gemm_bytes(kLdsBKMax));
+      else pc = m->compute_bf16 ? blocks_per_cu(gemm_f32_kernel<0, 0, 4, true, true>, 256, lds_f) : blocks_per_cu(gemm_f32_kernel<0, 0, 4, false, true>, 256, lds_f);
+    }
+  }
+  const int cus = m->cu_budget > 0 ? std::min(m->cu_budget, m->n_cus) : m->n_cus;
+  return pc > 0 && tiles <= (long)pc * cus;
+}
 
 static GemmArgs gemm_args(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
                           int epi) {
@@ -1037,6 +1432,8 @@ static inline size_t align4(size_t x) { return (x + 3) & ~size_t(3); }
 void mlp_plan_free(lipasr_mlp* m) {
   if (!m) return;
   if (m->ws) (void)hipFree(m->ws);
+  if (m->xc_gran) (void)hipFree(m->xc_gran);
+  if (m->xc_ctrl) (void)hipFree(m->xc_ctrl);
   delete m;
 }
 
@@ -1128,6 +1525,31 @@ int lipasr_mlp_create(lipasr_handle_t h, int n_layers, const int* widths, const 
     return LIPASR_ENOMEM;
   }
   (void)hipMemset(m->ws, 0, wo * sizeof(float));
+  // exchange epilogue state (round 5): granules and control words per BatchNorm layer and direction, all zero (tag 0 is never used)
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, h->device) == hipSuccess) m->n_cus = prop.multiProcessorCount;
+    m->xc_rt_max = std::min((max_batch + 31) / 32, 64);
+    size_t go = 0, co = 16;  // control word 0: the error word (its own 64-byte slot)
+    for (int dir = 0; dir < 2; ++dir)
+      for (int l = 0; l + 1 < n_layers; ++l) {
+        if (!m->L[l].bn) continue;
+        const size_t nblk = (size_t)(m->L[l].n_out + 31) / 32;
+        m->xc_gran_off[dir][l] = go; go += nblk * m->xc_rt_max * 128;
+        m->xc_ctrl_off[dir][l] = co; co += nblk * 32;
+      }
+    if (go > 0) {
+      if (hipMalloc(&m->xc_gran, go * sizeof(unsigned long long)) != hipSuccess || hipMalloc(&m->xc_ctrl, co * sizeof(unsigned)) != hipSuccess) {
+        (void)hipGetLastError();
+        if (m->xc_gran) (void)hipFree(m->xc_gran);
+        m->xc_gran = nullptr; m->xc_ctrl = nullptr;  // no exchange state: the launch chain is used
+      } else {
+        (void)hipMemset(m->xc_gran, 0, go * sizeof(unsigned long long));
+        (void)hipMemset(m->xc_ctrl, 0, co * sizeof(unsigned));
+        m->xc_err = reinterpret_cast<int*>(m->xc_ctrl);
+      }
+    }
+  }
   h->mlps.push_back(m);
   *out = m;
   return LIPASR_OK;
@@ -1315,10 +1737,21 @@ static int train_fwd_bwd_impl(lipasr_mlp_t m, const float* params, float* bnstat
     const bool last = (l == Lc - 1);
     float* outp = last ? (ws + m->offLogits) : (ws + L.offA);
     const bool fuse_ce = last && C <= 32;  // softmax, loss and (p - y) / B in the last GEMM's epilogue
+    // BatchNorm inside this GEMM (exchange epilogue) where the whole grid can be resident; not with synchronized BatchNorm,
+    // whose sums leave the device between the GEMM and the apply kernel
+    const bool bnx = !last && L.bn && sa.seg < 0 && bnx_fits(m, true, batch, L.n_out, L.n_in);
     GemmArgs g = gemm_args(hin, L.n_in, params + L.offW, L.n_out, outp, L.n_out, batch, L.n_out, L.n_in,
-                           last ? (fuse_ce ? EPI_BIAS_SOFTMAX_CE : EPI_BIAS) : (L.bn ? EPI_BIAS_RELU_STATS : EPI_BIAS_RELU));
+                           last ? (fuse_ce ? EPI_BIAS_SOFTMAX_CE : EPI_BIAS) : (L.bn ? (bnx ? EPI_BIAS_RELU_BNX : EPI_BIAS_RELU_STATS) : EPI_BIAS_RELU));
     g.bias = params + L.offb;
     g.part = part;
+    if (bnx) {
+      g.xc_gran = m->xc_gran + m->xc_gran_off[0][l]; g.xc_ctrl = m->xc_ctrl + m->xc_ctrl_off[0][l]; g.xc_err = m->xc_err; g.xc_rt_max = m->xc_rt_max;
+      g.Bstat = bstat;
+      g.h_out = ws + L.offH;
+      g.gamma = params + L.offg; g.beta = params + L.offbe;
+      g.mmean_w = bnstate + L.offmm; g.mvar_w = bnstate + L.offmv; g.save_w = ws + L.offMean;
+      g.drop = drop_for_layer(m, l, dropout);
+    }
     if (fuse_ce) {
       g.y = y_onehot;
       g.inv_batch = inv_batch;
@@ -1339,7 +1772,7 @@ static int train_fwd_bwd_impl(lipasr_mlp_t m, const float* params, float* bnstat
       }
     }
     if (!last && L.bn) ++cur;  // exchange point: the partial sums of a, a^2 are complete
-    if (!last && L.offH != L.offA && LP_ON) {
+    if (!last && L.offH != L.offA && LP_ON && !bnx) {
       BnFwdArgs b;
       memset(&b, 0, sizeof(b));
       b.a = ws + L.offA; b.h = ws + L.offH; b.B = batch; b.N = L.n_out; b.has_bn = L.bn ? 1 : 0;
@@ -1375,13 +1808,21 @@ static int train_fwd_bwd_impl(lipasr_mlp_t m, const float* params, float* bnstat
     const MlpLayer& P = m->L[l - 1];
     const float* gin = (l == Lc - 1) ? (ws + m->offDzLast) : (ws + L.offDz);
     // dh_prev[B][n_in] = gin[B][n_out] * W^T
-    float* out1 = P.bn ? tmp : (ws + P.offDz);
+    const bool bnx = P.bn && sa.seg < 0 && bnx_fits(m, false, batch, L.n_in, L.n_out);
+    float* out1 = (P.bn && !bnx) ? tmp : (ws + P.offDz);
     GemmArgs gx = gemm_args(gin, L.n_out, params + L.offW, L.n_out, out1, L.n_in, batch, L.n_in, L.n_out,
-                            P.bn ? EPI_DH_STATS : EPI_DZ_NOBN);
+                            P.bn ? (bnx ? EPI_DH_BNX : EPI_DH_STATS) : EPI_DZ_NOBN);
     gx.aux = ws + P.offA;
     gx.drop = drop_for_layer(m, l - 1, dropout);
     gx.part = part;
     if (P.bn) gx.save_mean = ws + P.offMean;
+    if (bnx) {
+      gx.xc_gran = m->xc_gran + m->xc_gran_off[1][l - 1]; gx.xc_ctrl = m->xc_ctrl + m->xc_ctrl_off[1][l - 1]; gx.xc_err = m->xc_err;
+      gx.xc_rt_max = m->xc_rt_max;
+      gx.Bstat = bstat; gx.grad_scale = sa.grad_scale;
+      gx.gamma = params + P.offg;
+      gx.dgamma = grads + P.offg; gx.dbeta = grads + P.offbe;
+    }
     gx.bf16 = m->compute_bf16;
     gx.lds_min_tiles = m->lds_min_tiles;
     if (LP_ON) {
@@ -1394,7 +1835,7 @@ static int train_fwd_bwd_impl(lipasr_mlp_t m, const float* params, float* bnstat
       }
     }
     if (P.bn) ++cur;  // exchange point: the partial sums of g, g xhat are complete
-    if (P.bn && LP_ON) {
+    if (P.bn && LP_ON && !bnx) {
       BnBwdArgs b;
       memset(&b, 0, sizeof(b));
       b.g = tmp; b.a = ws + P.offA; b.dz = ws + P.offDz; b.B = batch; b.N = P.n_out;
@@ -1603,6 +2044,28 @@ int lipasr_mlp_output_vjp(lipasr_mlp_t m, const float* params, const float* bnst
 int lipasr_mlp_set_gemm_tiles(lipasr_mlp_t m, int lds_min_tiles) {
   LP_CHECK_ARG(m != nullptr && lds_min_tiles >= 0, "lipasr_mlp_set_gemm_tiles: bad argument");
   m->lds_min_tiles = lds_min_tiles;
+  return LIPASR_OK;
+}
+
+int lipasr_mlp_set_fuse_bn(lipasr_mlp_t m, int mode) {
+  LP_CHECK_ARG(m != nullptr && (mode == 0 || mode == 1), "lipasr_mlp_set_fuse_bn: bad argument");
+  m->fuse_bn = mode;
+  return LIPASR_OK;
+}
+
+int lipasr_mlp_set_cu_budget(lipasr_mlp_t m, int n_cus) {
+  LP_CHECK_ARG(m != nullptr && n_cus >= 0, "lipasr_mlp_set_cu_budget: bad argument");
+  m->cu_budget = n_cus;
+  return LIPASR_OK;
+}
+
+int lipasr_mlp_exchange_errors(lipasr_mlp_t m, int* errors_host) {
+  LP_CHECK_ARG(m != nullptr && errors_host != nullptr, "lipasr_mlp_exchange_errors: null argument");
+  *errors_host = 0;
+  if (!m->xc_err) return LIPASR_OK;
+  DeviceGuard g(m->ctx->device);
+  LP_HIP(hipMemcpy(errors_host, m->xc_err, sizeof(int), hipMemcpyDeviceToHost));  // synchronises with the device
+  if (*errors_host) LP_HIP(hipMemset(m->xc_err, 0, sizeof(int)));
   return LIPASR_OK;
 }
 

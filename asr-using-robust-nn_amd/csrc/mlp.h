@@ -36,5 +36,17 @@ struct lipasr_mlp {
   size_t offLogits = 0, offProb = 0, offDzLast = 0, offG0 = 0, offG1 = 0, offG2 = 0, offPart = 0;
   int compute_bf16 = 0;  // lipasr_mlp_set_compute: 1 rounds the GEMM operands to bf16 at the MFMA (fp32 accumulate)
   int lds_min_tiles = 0;  // lipasr_mlp_set_gemm_tiles: training GEMMs take the LDS-tiled kernel from this many 64x64 tiles (0 = default)
-
+  // Round 5: training-mode BatchNorm inside the GEMM that produces its input (dense.hip, "exchange epilogue").  The row tiles
+  // of a 32- (or 64-) column block hand each other their column partial sums through memory INSIDE the launch, so the apply
+  // kernels and their launch boundaries go.  Per BatchNorm layer and direction: granules {tag, value} and two control words
+  // per 32-column block.
+  int fuse_bn = 1;        // lipasr_mlp_set_fuse_bn: 0 = the launch chain (GEMM + apply kernel), the parity reference
+  int cu_budget = 0;      // lipasr_mlp_set_cu_budget: CUs the stream this plan runs on may use (0 = all of the device)
+  int n_cus = 0;
+  int xc_rt_max = 0;      // row tiles the granule regions hold (<= 64)
+  unsigned long long* xc_gran = nullptr;
+  unsigned* xc_ctrl = nullptr;
+  int* xc_err = nullptr;  // device word: an exchange gave up (a workgroup of its column block never became resident)
+  size_t xc_gran_off[2][LIPASR_MAX_LAYERS] = {};  // [forward | backward][layer], in granules
+  size_t xc_ctrl_off[2][LIPASR_MAX_LAYERS] = {};  // in 32-bit words
 };

@@ -93,6 +93,9 @@ PROTOTYPES = {
     "lipasr_mlp_input_grad": (i32, [c_h, c_f, c_f, c_f, c_f, i32, c_f, c_s]),
     "lipasr_mlp_set_compute": (i32, [c_h, i32]),
     "lipasr_mlp_set_gemm_tiles": (i32, [c_h, i32]),
+    "lipasr_mlp_set_fuse_bn": (i32, [c_h, i32]),
+    "lipasr_mlp_set_cu_budget": (i32, [c_h, i32]),
+    "lipasr_mlp_exchange_errors": (i32, [c_h, C.POINTER(C.c_int)]),
     "lipasr_mlp_output_vjp": (i32, [c_h, c_f, c_f, c_f, c_f, i32, i32, c_f, c_f, c_s]),
     "lipasr_mlp_attack_step": (i32, [c_h, c_f, c_f, c_f, c_f, c_f, i32, f32, f32, c_s]),
     "lipasr_mlp_own_labels": (i32, [c_h, c_f, c_f, c_f, i32, c_f, c_s]),

@@ -388,6 +388,10 @@ class Model:
         N.register_owner(self)
         if self._compute_dtype == "bfloat16":
             N.check(N.lib.lipasr_mlp_set_compute(plan, 1))
+        import os as _os
+
+        if _os.environ.get("LIPASR_FUSE_BN", "1") == "0":  # A/B knob: BatchNorm as launches of its own (the round-4 chain)
+            N.check(N.lib.lipasr_mlp_set_fuse_bn(plan, 0))
         n_params, n_state = N.sz(), N.sz()
         N.check(N.lib.lipasr_mlp_sizes(plan, C.byref(n_params), C.byref(n_state)))
         dev = self._device
@@ -411,6 +415,13 @@ class Model:
         self._loss_rows = torch.zeros(self._max_batch, device=dev)
         self._correct_rows = torch.zeros(self._max_batch, device=dev)
         self._init_weights()
+
+    def exchange_errors(self):
+        """Non-zero if a fused BatchNorm exchange (lipasr_mlp_set_fuse_bn) gave up since the last call; synchronises."""
+        e = C.c_int(0)
+        if getattr(self, "_plan", None):
+            N.check(N.lib.lipasr_mlp_exchange_errors(self._plan, C.byref(e)))
+        return e.value
 
     def close(self):
         """Frees the native classifier plan (its workspace).  Idempotent; the tensors stay readable."""

@@ -221,7 +221,10 @@ class TrainPipeline:
                 # on part of the chip the LDS-tiled GEMM pays from fewer tiles on (layer 2 forward, the dX GEMM into layer 2:
                 # 128 tiles): -16 us on the classifier's graph at 160 CUs (PGD, which keeps every CU, loses 8 % with it)
                 N.check(N.lib.lipasr_mlp_set_gemm_tiles(self.model._plan, 128))
-                self._gemm_tiles_set = True  # the pipeline owns this setting: close() puts the model's plan back
+                # the fused BatchNorm exchange spins until a column block's workgroups are all resident: tell the plan how many
+                # CUs its stream really has (round 5)
+                N.check(N.lib.lipasr_mlp_set_cu_budget(self.model._plan, self.train_cus))
+                self._gemm_tiles_set = True  # the pipeline owns these settings: close() puts the model's plan back
         else:
             self._own_queue_train_stream(n_cu)
         return torch.cuda.ExternalStream(st.value, device=self.dev)
@@ -519,6 +522,10 @@ class TrainPipeline:
         self.mfcc_stream.synchronize()
         self.stream.synchronize()
         self._check_flags()
+        if self.model.exchange_errors():
+            raise RuntimeError("TrainPipeline: a BatchNorm exchange inside a GEMM gave up after 2 s (workgroups of one column block were never "
+                               "resident together: is the plan's CU budget larger than its stream's CU mask?); the step's results are invalid. "
+                               "LIPASR_FUSE_BN=0 uses the launch chain")
 
     @property
     def mfcc_stream_kind(self):
@@ -563,6 +570,7 @@ class TrainPipeline:
         if self._gemm_tiles_set and getattr(self.model, "_plan", None):
             self._gemm_tiles_set = False
             N.lib.lipasr_mlp_set_gemm_tiles(self.model._plan, 0)  # back to the library's default threshold
+            N.lib.lipasr_mlp_set_cu_budget(self.model._plan, 0)
         if not self._custom_ex:
             self.ex.close()  # the pipeline's own MFCC plan
         if pending is not None:

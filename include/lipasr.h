@@ -289,6 +289,23 @@ int lipasr_mlp_set_compute(lipasr_mlp_t m, int mode);
  * re-capture HIP graphs after changing it. */
 int lipasr_mlp_set_gemm_tiles(lipasr_mlp_t m, int lds_min_tiles);
 
+/* (round 5) Training-mode BatchNorm (train_constraints.py:68 ff.: BatchNormalization() after every hidden Dense) INSIDE the GEMM
+ * that produces its input: the row tiles of a column block exchange their column partial sums through memory during the launch
+ * (8-byte {tag, value} granules) and every tile normalises the values it still holds, forward and backward -- the ten
+ * bn_apply_* launches of a step and their round trips go.  Bitwise reproducible (fixed summation order, no float atomics), equal
+ * to the launch chain up to the order of the partial sums (1e-6).  mode 1 (default): wherever the launch's whole grid can be
+ * resident on the CUs the plan may use and the batch has at most 64 row tiles; mode 0: the launch chain everywhere (the parity
+ * reference).  Not used with synchronized BatchNorm (lipasr_mlp_train_segment). */
+int lipasr_mlp_set_fuse_bn(lipasr_mlp_t m, int mode);
+/* (round 5) How many CUs the stream this plan is launched on may use (a CU-masked stream: lipasr_stream_create_masked);
+ * 0 = all of the device (default).  The exchange above spins until its column block's workgroups have all published, so the
+ * library must know how many can be resident: a plan run on a masked stream WITHOUT this call may stall (each exchange gives up
+ * after 2 s and sets the error count below; it never hangs the queue). */
+int lipasr_mlp_set_cu_budget(lipasr_mlp_t m, int n_cus);
+/* (round 5) errors_host (HOST int): non-zero if an exchange gave up since the last call (then the results of that step are
+ * not valid); synchronises with the device and clears the word. */
+int lipasr_mlp_exchange_errors(lipasr_mlp_t m, int* errors_host);
+
 /* model.predict (train_constraints.py:109, attacks.py:344): inference mode (BN moving statistics,
  * no dropout).  probs and/or logits [batch][classes], either may be NULL. */
 int lipasr_mlp_predict(lipasr_mlp_t m, const float* params, const float* bnstate, const float* x,

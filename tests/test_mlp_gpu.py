@@ -367,3 +367,91 @@ def test_bf16_operand_mode(cuda):
     assert accs["float32"] > 0.9 and abs(accs["float32"] - accs["bfloat16"]) <= 0.03, accs
     with pytest.raises(ValueError):
         K.Model(inputs=inp, outputs=o, compute_dtype="float16")
+
+
+# ------------------------------------------------------------------------------------------------
+# Round 5: training-mode BatchNorm inside the producing GEMM (the exchange epilogue)
+# ------------------------------------------------------------------------------------------------
+def _train_state(m):
+    return m._grads.clone(), m._bnstate.clone(), m._loss_rows.clone()
+
+
+@pytest.mark.parametrize("widths,batch,drop", [
+    ((880, 1024, 512, 256, 128, 64, 10), 1024, True),    # the reference's model at the bench's batch: the 64x64 LDS kernel and the fragment kernel
+    ((880, 1024, 512, 256, 128, 64, 10), 512, True),     # the reference's own batch
+    ((880, 1024, 512, 256, 128, 64, 10), 182, False),    # its last, partial batch: a ragged last row tile
+    ((100, 72, 50, 33, 10), 77, True),                    # widths that are no multiple of 4 or 32, ragged rows
+    ((2020, 1024, 512, 256, 128, 64, 20), 2048, False),  # the speaker-recognition shape, 64 row tiles of 32 (the regions' limit)
+])
+def test_batchnorm_inside_the_gemm_equals_the_launch_chain(cuda, widths, batch, drop):
+    """lipasr_mlp_set_fuse_bn: the same training step with BatchNorm finished inside the producing GEMMs (column sums exchanged
+    between the row tiles of a column block during the launch) and as GEMM + bn_apply launches.  The partial sums are the same
+    fp32 numbers; they are added in fp64 in a different fixed order, so the two agree to rounding level (not bitwise), and each
+    path is bitwise reproducible from launch to launch.  Also checks that no exchange gave up (error word)."""
+    from lipasr import _native as N
+
+    spec = [P.LayerSpec(widths[i], widths[i + 1], i + 2 < len(widths), (0.1 if (drop and i < 3 and i + 2 < len(widths)) else 0.0), True)
+            for i in range(len(widths) - 1)]
+    p = _random_state(spec, 4)
+    rng = np.random.default_rng(batch + len(widths))
+    x = dev(rng.standard_normal((batch, widths[0])).astype(np.float32))
+    y = dev(P.to_categorical(rng.integers(0, widths[-1], batch), widths[-1]))
+    out = {}
+    for mode in (0, 1):
+        m = build_model(spec, max_batch=batch)
+        load_params(m, p)
+        N.check(N.lib.lipasr_mlp_set_fuse_bn(m._plan, mode))
+        m.train_fwd_bwd(x, y)                     # Philox dropout: same key on both paths
+        first = _train_state(m)
+        m.apply_adam()
+        after = (m._params.clone(), m._bnstate.clone())
+        # again from the same state: bitwise equal to the first launch (and the generation words have moved on)
+        load_params(m, p)
+        m._step.zero_()
+        m.train_fwd_bwd(x, y)
+        second = _train_state(m)
+        for a, b in zip(first, second):
+            assert torch.equal(a, b), f"mode {mode}: not reproducible"
+        assert m.exchange_errors() == 0
+        out[mode] = (first, after)
+        m.close()
+    (g0, s0, l0), (p0, b0) = out[0]
+    (g1, s1, l1), (p1, b1) = out[1]
+    scale = float(g0.abs().max())
+    assert float((g0 - g1).abs().max()) <= 2e-6 * scale + 1e-12, float((g0 - g1).abs().max()) / scale
+    torch.testing.assert_close(s1, s0, rtol=1e-6, atol=1e-7)     # moving statistics
+    torch.testing.assert_close(l1[:batch], l0[:batch], rtol=1e-6, atol=1e-7)
+    assert float(b1.sub(b0).abs().max()) <= 1e-6 * float(b0.abs().max())
+
+
+def test_batchnorm_inside_the_gemm_over_thirty_steps(cuda):
+    """VERDICT r4 item 1's bar for a restructured step: parameters within 1e-6 (of the largest weight) of the launch-chain path
+    after 30 training steps with the constraint, dropout on."""
+    from lipasr import _native as N
+    from lipasr.Constraints import simple_norm_constraint
+
+    spec = P.vd_constrained_spec()
+    p = P.init_params(spec, seed=21, dtype=np.float32, nonneg_init=True)
+    rng = np.random.default_rng(8)
+    xs = dev(rng.standard_normal((3 * 256, 880)).astype(np.float32))
+    ys = dev(P.to_categorical(rng.integers(0, 10, 3 * 256), 10))
+    res = []
+    for mode in (0, 1):
+        m = build_model(spec, max_batch=256)
+        load_params(m, p)
+        N.check(N.lib.lipasr_mlp_set_fuse_bn(m._plan, mode))
+        cst = simple_norm_constraint(0.1, [])
+        cst.set_model(m)
+        for i in range(30):
+            s = (i % 3) * 256
+            m.train_fwd_bwd(xs[s:s + 256], ys[s:s + 256])
+            m.apply_adam()
+            cst.on_batch_end(i)
+        assert m.exchange_errors() == 0
+        res.append((m._params.clone(), m._bnstate.clone()))
+        m.close()
+    wmax = float(res[0][0].abs().max())
+    d = float((res[0][0] - res[1][0]).abs().max())
+    print(f"\nparameters after 30 steps: max |fused - chain| = {d:.3e} ({d / wmax:.2e} of the largest weight)")
+    assert d <= 1e-6 * wmax + 1e-9, (d, wmax)
+    assert float((res[0][1] - res[1][1]).abs().max()) <= 1e-5 * float(res[0][1].abs().max())
