@@ -213,15 +213,23 @@ constexpr long long kXcTimeoutTicks = 200000000LL;  // 2 s of the 100 MHz wall c
 
 // NT threads; CB columns per block (32: the fragment kernel, 64: the LDS-tiled kernel).  mine[2 CB]: this tile's partial sums
 // (LDS).  On return tot[2 CB] (LDS, fp64) holds the sums over all n_rt row tiles.  sbuf: LDS, (NT / (2 CB)) x 2 CB doubles.
+// this launch's tag for column block bx: the block's generation + 1.  Read at the START of the kernel (the round trip hides behind
+// the K loop; any time before this workgroup's own arrival is early enough: the generation cannot move before every row tile
+// of the block has arrived)
+template <int CB>
+__device__ __forceinline__ unsigned xc_tag(const XcView& xc, int bx) {
+  return __hip_atomic_load(xc.ctrl + (size_t)bx * (CB / 32) * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+}
+
 template <int NT, int CB>
-__device__ __forceinline__ void xc_exchange(const XcView& xc, int bx, int by, int n_rt, const float* mine, double* sbuf, double* tot) {
+__device__ __forceinline__ void xc_exchange(const XcView& xc, int bx, int by, int n_rt, const unsigned want, const float* mine, double* sbuf,
+                                            double* tot) {
   constexpr int NI = 2 * CB, PER = NT / NI, MAXK = 64 / PER;
   typedef unsigned long long u64;
   const int tid = threadIdx.x, item = tid % NI, rl = tid / NI;
   const int jblk = bx * (CB / 32);
   unsigned* cw = xc.ctrl + (size_t)jblk * 32;
   u64* g = xc.gran + (size_t)jblk * xc.rt_max * 128;
-  const unsigned want = __hip_atomic_load(cw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
   if (tid < NI)
     __hip_atomic_store(g + (size_t)by * 128 + tid, ((u64)want << 32) | (u64)__float_as_uint(mine[tid]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   float v[MAXK];
@@ -245,6 +253,9 @@ __device__ __forceinline__ void xc_exchange(const XcView& xc, int bx, int by, in
     }
     __builtin_amdgcn_s_sleep(4);
   }
+  // arrive now: the returning atomic's round trip runs beside the sums, the normalisation and the stores below
+  unsigned old = 0;
+  if (tid == 0) old = __hip_atomic_fetch_add(cw + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   double s = 0.0;
 #pragma unroll
   for (int k = 0; k < MAXK; ++k) s += (double)v[k];  // (slots past n_rt hold 0)
@@ -256,12 +267,9 @@ __device__ __forceinline__ void xc_exchange(const XcView& xc, int bx, int by, in
     for (int r = 0; r < PER; ++r) t += sbuf[r * NI + tid];
     tot[tid] = t;
   }
-  if (tid == 0) {
-    const unsigned old = __hip_atomic_fetch_add(cw + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (old == (unsigned)n_rt - 1u) {  // the last row tile of the block: nobody reads the generation any more in this launch
-      __hip_atomic_store(cw + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(cw, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+  if (tid == 0 && old == (unsigned)n_rt - 1u) {  // the last row tile of the block: nobody reads the generation any more in this launch
+    __hip_atomic_store(cw + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(cw, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
 }
@@ -353,17 +361,38 @@ __device__ __forceinline__ void bnx_column(const GemmArgs& g, const int by, cons
   }
 }
 
-// the element before the exchange: value kept in registers, its two statistics; forward also stores a
+// The per-element operands of the exchange epilogue, requested BEFORE the K-split partial tiles meet in LDS (their round trip
+// runs beside that barrier): forward the bias, backward the post-ReLU activation and the column's saved mean / rstd.
+struct BnxPre {
+  float p0[4], p1[4], p2[4];
+};
+__device__ __forceinline__ void bnx_prefetch(const GemmArgs& g, const int gm, const int gn, BnxPre& q) {
+  const bool rv = gm < g.M;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const bool cv = rv && gn + e < g.N;
+    if (g.epi == EPI_BIAS_RELU_BNX) {
+      q.p0[e] = cv ? g.bias[gn + e] : 0.0f;
+      q.p1[e] = 0.0f; q.p2[e] = 0.0f;
+    } else {
+      q.p0[e] = cv ? g.aux[(size_t)gm * g.ldc + gn + e] : 0.0f;
+      q.p1[e] = cv ? g.save_mean[gn + e] : 0.0f;
+      q.p2[e] = cv ? g.save_mean[g.N + gn + e] : 0.0f;
+    }
+  }
+}
+
+// the element before the exchange: value kept in registers, its two statistics
 __device__ __forceinline__ void bnx_elem(const GemmArgs& g, const int step, const bool cv, const int gm, const int gn, const float acc,
-                                         float& val, float& av, float& s1, float& s2) {
+                                         const BnxPre& q, const int e, float& val, float& av, float& s1, float& s2) {
   if (g.epi == EPI_BIAS_RELU_BNX) {
-    const float a = cv ? fmaxf(acc + g.bias[gn], 0.0f) : 0.0f;
+    const float a = cv ? fmaxf(acc + q.p0[e], 0.0f) : 0.0f;
     val = a; av = a; s1 = a; s2 = a * a;
   } else {
     const size_t idx = (size_t)gm * g.ldc + gn;
     const float gg = cv ? acc * dropout_mult(g.drop, step, idx) : 0.0f;
-    const float a = cv ? g.aux[idx] : 0.0f;
-    const float xh = cv ? (a - g.save_mean[gn]) * g.save_mean[g.N + gn] : 0.0f;
+    const float a = q.p0[e];
+    const float xh = cv ? (a - q.p1[e]) * q.p2[e] : 0.0f;
     val = gg; av = a; s1 = gg; s2 = gg * xh;
   }
 }
@@ -388,6 +417,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
   const int ai = min(row_a, m_real - 1);
   const int bj = min(n0 + r, g.N - 1);
 
+  unsigned xtag = 0;
+  if constexpr (X) xtag = xc_tag<32>(XcView{g.xc_gran, g.xc_ctrl, g.xc_err, g.xc_rt_max}, bx);
   f32x16 acc;
 #pragma unroll
   for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
@@ -417,6 +448,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
     for (int q = 0; q < 8; ++q) { a0[q] = a1[q]; b0[q] = b1[q]; }
     c = cn;
   }
+  BnxPre xpre;
+  if constexpr (X && NW == 4) bnx_prefetch(g, m0 + (tid >> 3), n0 + (tid & 7) * 4, xpre);
   // C/D map of one 32x32 accumulator: col = lane & 31, row = (q & 3) + 8 (q >> 2) + 4 (lane >> 5)
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
@@ -439,7 +472,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
       const float accv[4] = {s.x, s.y, s.z, s.w};
       float val[1][4], av[1][4], c1[4], c2[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) bnx_elem(g, step, gm1[0] < g.M && gn + e < g.N, gm1[0], gn + e, accv[e], val[0][e], av[0][e], c1[e], c2[e]);
+      for (int e = 0; e < 4; ++e) bnx_elem(g, step, gm1[0] < g.M && gn + e < g.N, gm1[0], gn + e, accv[e], xpre, e, val[0][e], av[0][e], c1[e], c2[e]);
       if (g.epi == EPI_BIAS_RELU_BNX && gm1[0] < g.M) {  // the post-ReLU activations: the backward pass reads them
         float* crow = g.C + (size_t)gm1[0] * g.ldc;
         if (gn + 3 < g.N && ((g.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(crow) & 15) == 0)) {
@@ -479,7 +512,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
       }
       __syncthreads();
       XcView xc{g.xc_gran, g.xc_ctrl, g.xc_err, g.xc_rt_max};
-      xc_exchange<256, 32>(xc, bx, by, n_row_tiles, mine, sbuf, tot);
+      xc_exchange<256, 32>(xc, bx, by, n_row_tiles, xtag, mine, sbuf, tot);
       if (tid < TS) bnx_column(g, by, n0 + tid, tid, TS, tot, colp);
       __syncthreads();
       bnx_finish<1>(g, step, gm1, gn, val, av, colp, TS, c4);
@@ -712,6 +745,8 @@ __device__ __forceinline__ void gemm_lds_tile(const GemmArgs& g, const int bx, c
   const int m_real = g.ones_row ? g.M - 1 : g.M;
   const int nst = (g.K + BK - 1) / BK;
   const bool ones = g.ones_row != 0;
+  unsigned xtag = 0;
+  if constexpr (X) xtag = xc_tag<64>(XcView{g.xc_gran, g.xc_ctrl, g.xc_err, g.xc_rt_max}, bx);
   f32x16 acc;
 #pragma unroll
   for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
@@ -773,6 +808,11 @@ __device__ __forceinline__ void gemm_lds_tile(const GemmArgs& g, const int bx, c
     kstep(t, t0, t1);                    // even step: slot 0 is free (tile t is in LDS), slot 1 holds tile t+1
     if (t + 1 < nst) kstep(t + 1, t1, t0);  // odd step: the roles swap
   }
+  BnxPre xpre[2];
+  if constexpr (X) {
+    bnx_prefetch(g, m0 + (tid >> 4), n0 + (tid & 15) * 4, xpre[0]);
+    bnx_prefetch(g, m0 + (tid >> 4) + 32, n0 + (tid & 15) * 4, xpre[1]);
+  }
   // accumulators -> LDS as two 64x64 partial tiles (one per K half), then the shared epilogue shape
   float* red = lds;
 #pragma unroll
@@ -797,7 +837,7 @@ __device__ __forceinline__ void gemm_lds_tile(const GemmArgs& g, const int bx, c
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float t1, t2;
-        bnx_elem(g, step, gm2[pass] < g.M && gn + e < g.N, gm2[pass], gn + e, accv[e], val[pass][e], av[pass][e], t1, t2);
+        bnx_elem(g, step, gm2[pass] < g.M && gn + e < g.N, gm2[pass], gn + e, accv[e], xpre[pass], e, val[pass][e], av[pass][e], t1, t2);
         c1[e] += t1;
         c2[e] += t2;
       }
@@ -838,7 +878,7 @@ __device__ __forceinline__ void gemm_lds_tile(const GemmArgs& g, const int bx, c
     }
     __syncthreads();
     XcView xc{g.xc_gran, g.xc_ctrl, g.xc_err, g.xc_rt_max};
-    xc_exchange<512, 64>(xc, bx, by, n_row_tiles, mine, sbuf, tot);
+    xc_exchange<512, 64>(xc, bx, by, n_row_tiles, xtag, mine, sbuf, tot);
     if (tid < TS) bnx_column(g, by, n0 + tid, tid, TS, tot, colp);
     __syncthreads();
     bnx_finish<2>(g, step, gm2, gn, val, av, colp, TS, c4);
