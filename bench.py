@@ -114,6 +114,22 @@ def cpu_baseline(batch, warmup=5, steps=20):
 
 # rocprofv3 names of the three timed MFCC slots (what `roofline.dominant_kernel` must match in profiles/*kernel_stats.csv)
 MFCC_KERNELS = {"resample": "resample_persist_h2_kernel", "stft_mel": "stft_bdft_kernel", "dct": "dct_kernel"}
+
+
+def mfcc_kernel_names(fused=False):
+    """The three timed slots' kernel names for the ACTIVE stage mask (LIPASR_MFCC_MASK: 256 = the Stockham STFT kernel, 64 = the
+    round-2 one, 16 = the fp32 resampler; ADVICE r4: the names used to be hard-coded to the default path)."""
+    mask = int(os.environ.get("LIPASR_MFCC_MASK", "0") or 0)
+    names = dict(MFCC_KERNELS)
+    if fused:
+        names["resample"], names["stft_mel"] = "(inside mfcc_fused_kernel)", "mfcc_fused_kernel"
+    elif mask & 256:
+        names["stft_mel"] = "stft_mel2_kernel"
+    elif mask & 64:
+        names["stft_mel"] = "stft_mel_kernel"
+    if mask & 16 and not fused:
+        names["resample"] = "resample_persist_kernel"
+    return names
 MFCC_SOURCES = ("mfcc.hip", "stft_bdft.hip", "stft.h", "mfcc_tables.h")
 
 
@@ -499,13 +515,12 @@ def main():
             continue
     if args.int16:  # the committed counter passes ran on float32 clips
         traffic, traffic_src, traffic_fused = None, None, None
+    names = mfcc_kernel_names(bool(ex.get("mfcc_fused")))
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale,
-                "stage": "MFCC (K1 = mfcc_fused_kernel [resample + STFT + mel + dB, timed in the stft_mel slot] + dct_kernel)" if ex.get("mfcc_fused") else
-                         "MFCC (K1 = resample_persist_h2_kernel + stft_bdft_kernel [block-DFT STFT on the matrix pipe + mel + dB] + dct_kernel)",
-                "dominant_kernel": "mfcc_fused_kernel" if ex.get("mfcc_fused") and dom == "stft_mel" else
-                                   ("stft_mel2_kernel" if dom == "stft_mel" and (int(os.environ.get("LIPASR_MFCC_MASK", "0")) & 256) else MFCC_KERNELS[dom]),
-                "kernel_names": MFCC_KERNELS,
+                "stage": "MFCC (K1 = " + (" + ".join(dict.fromkeys(v for v in names.values() if not v.startswith("(")))) + ")",
+                "dominant_kernel": names[dom],
+                "kernel_names": names,
                 "algorithmic_bytes_per_utt": bytes_per_utt, "units_per_launch": batch,
                 "kernel_ms": {k: round(ms[k], 4) for k in ("resample", "stft_mel", "dct")},
                 "fp32_flop_frac": round(MFCC_FLOP_PER_UTT * batch / (stage_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 5) if stage_ms > 0 else 0.0,

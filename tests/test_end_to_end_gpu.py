@@ -172,6 +172,104 @@ def test_logit_bound_along_the_constrained_trajectory(cuda, clips):
     assert rows[3][2] < rows[2][2] < rows[1][2] < rows[0][2]  # the error follows the product norm down
 
 
+def test_logit_error_split_by_stage(cuda, clips):
+    """which stage carries the logit error of the early-training states?  For the weights after 0, 1 and 5
+    constrained steps (the states of test_logit_bound_along_the_constrained_trajectory) two crossed pairings against the all-oracle
+    logits (oracle features -> oracle classifier, float64):
+
+        K2 alone   oracle features (cast to float32) -> PRODUCT classifier
+        K1 alone   PRODUCT features -> oracle classifier                       with the block-DFT STFT kernel (default) and
+        both       PRODUCT features -> PRODUCT classifier                      with the Stockham STFT kernel (stage mask 256)
+
+    Measured on the MI355X (round 5; worst row of 2 366 rows / rows over 1e-3):
+
+        steps  ||W6^T..W1^T||        K2         K1 block-DFT     K1 Stockham     both block-DFT   both Stockham
+            0     3.1e+06      3.5e-03 / 1    4.4e-02 / 4      3.8e-02 / 4      4.7e-02 / 4      4.8e-02 / 4
+            1        8.09      8.2e-06 / 0    1.7e-03 / 2      1.8e-03 / 2      1.7e-03 / 2      1.8e-03 / 2
+            5       0.127      1.2e-06 / 0    8.5e-05 / 0      7.9e-05 / 0      8.5e-05 / 0      7.9e-05 / 0
+
+    Reading: the classifier alone (fp32 MFMA chains against float64) is 200 times inside the bound as soon as the network's gain
+    is O(1); the 1.6e-3 of step 1 comes with the product's FEATURES, equally with either STFT kernel, and "both" is "K1".  The
+    features of the two rows over the bound differ from the oracle's by at most 2.5e-5 STANDARDISED units (row median 5e-7) -- in
+    coefficient 0 (the sum of the 128 mel dB values / sqrt(128)) of late frames (36-42: the decay of the clip, rms 1e-2 under a
+    peak of 0.16), i.e. fp32 rounding of 128 logarithms added up, ~1e-3 dB -- and the whole set's worst standardised difference is
+    3.9e-5.  That is the MFCC stage at its fp32 floor (the oracle computes the same quantities in float64); 1.7e-3 is that 2.5e-5
+    times the network's gain of 8.1 relative to logits that are themselves small.  No cheap fix exists short of a float64 dB / DCT
+    tail, and none is needed from the fifth step on (gain 0.13: 8.5e-5)."""
+    from helpers import read_params
+    from lipasr.Constraints import simple_norm_constraint
+    from lipasr.attacks import StandardScaler
+    from lipasr.extract_features_construct_dataset import MfccExtractor
+    from lipasr.keras import Dataset
+
+    waves, labels, ref_feats = clips
+    spec = [P.LayerSpec(s.n_in, s.n_out, s.bn, 0.0, s.nonneg) for s in P.vd_constrained_spec()]
+    mean, scale = P.standard_scaler_fit(ref_feats)
+    x_ref = (ref_feats - mean) / scale
+    wt = dev(waves)
+
+    def product_features(mask):
+        ex = MfccExtractor(16000, 16000, 1024, cuda)
+        ex.set(0, mask)
+        raw = torch.cat([ex(wt[s:s + 1024]) for s in range(0, N_TEST, 1024)])
+        sc = StandardScaler().fit(raw)
+        f = torch.cat([ex(wt[s:s + 1024], 44, sc.mean_, sc.scale_) for s in range(0, N_TEST, 1024)])
+        ex.close()
+        return f
+
+    feats = {"block-DFT": product_features(0), "Stockham": product_features(256)}
+    x_ref_dev = dev(x_ref.astype(np.float32))
+
+    def rel_rows(got, ref):
+        return np.abs(got - ref).max(axis=1) / np.maximum(np.abs(ref).max(axis=1), 1e-6)
+
+    def logits_dev(m, x):
+        return torch.cat([m.predict_device(x[s:s + 1024], logits=True) for s in range(0, N_TEST, 1024)]).cpu().numpy()
+
+    table = []
+    for n_steps in (0, 1, 5):
+        m = build_model(spec, max_batch=1024, seed=9)
+        load_params(m, P.init_params(spec, seed=9, dtype=np.float32, nonneg_init=(n_steps == 0)))
+        if n_steps:  # the same trajectory as the test above: trained on the default path's features
+            x, y = feats["block-DFT"][:2048].cpu().numpy(), P.to_categorical(labels[:2048], 10)
+            ds = Dataset.from_tensor_slices((np.tile(x, (9, 1))[:512 * n_steps], np.tile(y, (9, 1))[:512 * n_steps])).batch(512)
+            m.fit(ds, epochs=1, verbose=0, callbacks=[simple_norm_constraint(0.1, [])])
+        p = read_params(m, spec)
+        ref = P.forward_infer(spec, p, x_ref, return_logits=True)
+        lip = float(np.linalg.norm(R_chain(p.W), ord=2))
+        row = {"steps": n_steps, "lip": lip, "K2": rel_rows(logits_dev(m, x_ref_dev), ref)}
+        for name, f in feats.items():
+            row[f"K1 {name}"] = rel_rows(P.forward_infer(spec, p, f.cpu().numpy().astype(np.float64), return_logits=True), ref)
+            row[f"both {name}"] = rel_rows(logits_dev(m, f), ref)
+        table.append(row)
+        if n_steps == 1:
+            # where the K1 error of the worst rows comes from
+            r = row["K1 block-DFT"]
+            worst = np.argsort(r)[-3:][::-1]
+            fd = np.abs(feats["block-DFT"].cpu().numpy().astype(np.float64) - x_ref)
+            for w in worst:
+                j = int(fd[w].argmax())
+                print(f"step 1, row {int(w)}: logit error {r[w]:.2e}; largest standardised feature difference {fd[w].max():.2e} at coefficient {j // 44}, frame {j % 44}; "
+                      f"row median feature difference {np.median(fd[w]):.1e}; clip peak |y| {np.abs(waves[w]).max():.3f}, "
+                      f"rms of that frame's samples {np.sqrt(np.mean(waves[w][max(0, (j % 44) * 372 - 743):(j % 44) * 372 + 743] ** 2)):.2e}")
+            print(f"all rows: standardised feature difference max {fd.max():.2e}, median row max {np.median(fd.max(axis=1)):.2e}")
+        m.close()
+    cols = ["K2", "K1 block-DFT", "K1 Stockham", "both block-DFT", "both Stockham"]
+    print("\nsteps  ||W6^T..W1^T||  " + "  ".join(f"{c:>22s}" for c in cols) + "      (worst row / rows > 1e-3)")
+    for row in table:
+        print(f"{row['steps']:5d}  {row['lip']:14.4g}  " + "  ".join(f"{row[c].max():14.2e} / {int((row[c] > 1e-3).sum()):5d}" for c in cols))
+    for row in table:
+        if row["lip"] < 10:  # the classifier alone is never what exceeds the bound once the network's gain is O(1)
+            assert row["K2"].max() <= 1e-4, (row["steps"], row["K2"].max())
+        if row["steps"] >= 5:
+            for c in cols:
+                assert row[c].max() <= 1e-3, (row["steps"], c, row[c].max())
+    # the two STFT kernels are interchangeable for this question
+    for row in table:
+        a, b = row["both block-DFT"], row["both Stockham"]
+        assert (a > 1e-3).sum() <= 0.005 * N_TEST and (b > 1e-3).sum() <= 0.005 * N_TEST
+
+
 def R_chain(w_list):
     from oracle import constraints_ref as R
 
