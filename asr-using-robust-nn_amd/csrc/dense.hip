@@ -89,6 +89,7 @@ struct GemmArgs {
   // (v_mfma_f32_32x32x16_bf16): BASELINE config 2's arithmetic; memory stays fp32.
   int bf16;
   int lds_min_tiles;  // host side only: 64x64 tiles from which launch_gemm takes the LDS-tiled kernel (0 = the default)
+  int xcd_map;        // 1: workgroup -> tile by xcd_tile() (a compact patch of the tile grid per XCD); 0: blockIdx as it comes
   // EPI_BIAS_RELU_BNX / EPI_DH_BNX (the exchange epilogue)
   unsigned long long* xc_gran;  // [32-column block][xc_rt_max][128] {tag, value}
   unsigned* xc_ctrl;            // [32-column block][32]: word 0 generation, word 1 arrivals
@@ -221,9 +222,11 @@ __device__ __forceinline__ unsigned xc_tag(const XcView& xc, int bx) {
   return __hip_atomic_load(xc.ctrl + (size_t)bx * (CB / 32) * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
 }
 
-template <int NT, int CB>
+// `mid`: work of every thread that does not depend on the exchange (the forward pass's store of the post-ReLU activations), run
+// while lane 0 waits for the block's other row tiles -- in front of the publish it would sit in the drain the counter waits for
+template <int NT, int CB, typename Mid>
 __device__ __forceinline__ void xc_exchange(const XcView& xc, int bx, int by, int n_rt, const unsigned want, const float* mine, double* sbuf,
-                                            double* tot) {
+                                            double* tot, Mid mid) {
   constexpr int NI = 2 * CB, PER = NT / NI, MAXK = 64 / PER;
   typedef unsigned long long u64;
   const int tid = threadIdx.x, item = tid % NI, rl = tid / NI;
@@ -232,9 +235,27 @@ __device__ __forceinline__ void xc_exchange(const XcView& xc, int bx, int by, in
   u64* g = xc.gran + (size_t)jblk * xc.rt_max * 128;
   if (tid < NI)
     __hip_atomic_store(g + (size_t)by * 128 + tid, ((u64)want << 32) | (u64)__float_as_uint(mine[tid]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // Waiting quietly: the granules carry their own tags, but a workgroup that swept them over and over while the block's other row
+  // tiles still computed put 16 KB of sc1 loads on the fabric every 1.5 us -- with 256 tiles on 160 CUs (two rounds) the first
+  // round's workgroups polled through the whole second round and the launch took 58 us instead of 36 + 6 (round 5; the guide's
+  // polling-cost row).  So a tile counts itself on the block's `published` word once its granule stores have drained, ONE lane
+  // polls that word with a pause between reads, and the granules are swept ONCE when it says every row tile is there.
+  // (Measured against it: the count without the drain and a sweep that repeats on an old tag -- config 2 0.3409 against 0.3352 ms,
+  // config 3 0.404 against 0.400: the repeated sweeps cost more than the drain.)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) __hip_atomic_fetch_add(cw + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  mid();
+  if (tid == 0 && n_rt > 0) {
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(cw + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)n_rt) {
+      __builtin_amdgcn_s_sleep(16);
+      if (wall_clock64() - t0 > kXcTimeoutTicks) { __hip_atomic_store(xc.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
+  }
+  __syncthreads();
   float v[MAXK];
-  const long long t0 = wall_clock64();
-  for (;;) {
+  {
     bool ok = true;
 #pragma unroll
     for (int k = 0; k < MAXK; ++k) {
@@ -246,12 +267,7 @@ __device__ __forceinline__ void xc_exchange(const XcView& xc, int bx, int by, in
         v[k] = __uint_as_float((unsigned)x);
       }
     }
-    if (__syncthreads_and(ok)) break;
-    if (__syncthreads_or(wall_clock64() - t0 > kXcTimeoutTicks)) {  // (uniform: every thread leaves or none)
-      if (tid == 0) __hip_atomic_store(xc.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      break;
-    }
-    __builtin_amdgcn_s_sleep(4);
+    if (!ok) __hip_atomic_store(xc.err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // a tag that is not this launch's: never expected
   }
   // arrive now: the returning atomic's round trip runs beside the sums, the normalisation and the stores below
   unsigned old = 0;
@@ -267,8 +283,9 @@ __device__ __forceinline__ void xc_exchange(const XcView& xc, int bx, int by, in
     for (int r = 0; r < PER; ++r) t += sbuf[r * NI + tid];
     tot[tid] = t;
   }
-  if (tid == 0 && old == (unsigned)n_rt - 1u) {  // the last row tile of the block: nobody reads the generation any more in this launch
+  if (tid == 0 && old == (unsigned)n_rt - 1u) {  // the last row tile of the block: nobody reads the generation or polls any more in this launch
     __hip_atomic_store(cw + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(cw + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(cw, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
@@ -397,6 +414,25 @@ __device__ __forceinline__ void bnx_elem(const GemmArgs& g, const int step, cons
   }
 }
 
+// XCD-aware workgroup -> tile map (speed only; nothing depends on where a workgroup really runs).  Workgroups are dealt
+// round-robin over the 8 XCDs by their linear id, each XCD has its own 4 MiB L2.  With the plain map (bx = id % ntx) XCD x gets the
+// column tiles x and x + 8 of EVERY row tile: it reads the whole A operand (3.6-4 MB for the 1024-row layers: its entire L2) and
+// an eighth of B.  Here the workgroups of one XCD (ids = x mod 8) take a compact gx x gy patch of the tile grid instead, e.g.
+// 8 x 4 tiles of the 16 x 16 grid of layer 1: a quarter of A and half of B, 2.7 MB, so both operands stay in that L2.
+// Bijective whenever it applies (ntx divisible by gx, nty by gy); otherwise the plain map.
+__device__ __forceinline__ void xcd_tile(const int L, const int ntx, const int nty, int& bx, int& by) {
+  int gx = 0, gy = 0;
+  if ((ntx & 1) == 0 && (nty & 3) == 0) { gx = 2; gy = 4; }
+  else if ((ntx & 3) == 0 && (nty & 1) == 0) { gx = 4; gy = 2; }
+  else if ((nty & 7) == 0) { gx = 1; gy = 8; }
+  else if ((ntx & 7) == 0) { gx = 8; gy = 1; }
+  if (gx == 0) { bx = L % ntx; by = L / ntx; return; }
+  const int xcd = L & 7, q = L >> 3, pw = ntx / gx, ph = nty / gy;
+  (void)ph;
+  bx = (xcd % gx) * pw + q % pw;
+  by = (xcd / gx) * ph + q / pw;
+}
+
 // One workgroup = one 32x32 output tile; its NW wavefronts (4, or 16 for small outputs with a long K) split K
 // in 16-deep chunks, round-robin.  Operand fragments go global/L2 -> VGPR directly, one chunk ahead of the MFMAs.
 template <int AMODE, int BMODE, int NW, bool BF, bool X = false>  // X: the exchange epilogue (its own instances: with it as a run-time
@@ -473,16 +509,6 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
       float val[1][4], av[1][4], c1[4], c2[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) bnx_elem(g, step, gm1[0] < g.M && gn + e < g.N, gm1[0], gn + e, accv[e], xpre, e, val[0][e], av[0][e], c1[e], c2[e]);
-      if (g.epi == EPI_BIAS_RELU_BNX && gm1[0] < g.M) {  // the post-ReLU activations: the backward pass reads them
-        float* crow = g.C + (size_t)gm1[0] * g.ldc;
-        if (gn + 3 < g.N && ((g.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(crow) & 15) == 0)) {
-          *reinterpret_cast<float4*>(crow + gn) = make_float4(val[0][0], val[0][1], val[0][2], val[0][3]);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (gn + e < g.N) crow[gn + e] = val[0][e];
-        }
-      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
 #pragma unroll
@@ -512,7 +538,18 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
       }
       __syncthreads();
       XcView xc{g.xc_gran, g.xc_ctrl, g.xc_err, g.xc_rt_max};
-      xc_exchange<256, 32>(xc, bx, by, n_row_tiles, xtag, mine, sbuf, tot);
+      xc_exchange<256, 32>(xc, bx, by, g.Bstat < 0 ? 0 : n_row_tiles, xtag, mine, sbuf, tot, [&]() {  // (Bstat < 0: timing probe, below)
+        if (g.epi == EPI_BIAS_RELU_BNX && gm1[0] < g.M) {  // the post-ReLU activations: the backward pass reads them
+          float* crow = g.C + (size_t)gm1[0] * g.ldc;
+          if (gn + 3 < g.N && ((g.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(crow) & 15) == 0)) {
+            *reinterpret_cast<float4*>(crow + gn) = make_float4(val[0][0], val[0][1], val[0][2], val[0][3]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (gn + e < g.N) crow[gn + e] = val[0][e];
+          }
+        }
+      });
       if (tid < TS) bnx_column(g, by, n0 + tid, tid, TS, tot, colp);
       __syncthreads();
       bnx_finish<1>(g, step, gm1, gn, val, av, colp, TS, c4);
@@ -643,7 +680,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
 
 template <int AMODE, int BMODE, int NW, bool BF = false, bool X = false>  // BF: operands rounded to bf16 at the MFMA (compile-time: a
 __global__ __launch_bounds__(64 * NW) void gemm_f32_kernel(GemmArgs g) {  // run-time switch cost the fp32 path 6 %)
-  gemm_tile<AMODE, BMODE, NW, BF, X>(g, blockIdx.x, blockIdx.y, gridDim.y);
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (g.xcd_map) xcd_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x, gridDim.y, bx, by);
+  gemm_tile<AMODE, BMODE, NW, BF, X>(g, bx, by, gridDim.y);
 }
 
 // Several independent GEMMs of one (AMODE, BMODE) in ONE launch: the six weight-gradient GEMMs of a training step
@@ -662,8 +701,10 @@ __global__ __launch_bounds__(64 * NW) void gemm_f32_grouped_kernel(GemmGroup grp
   while (p + 1 < grp.n && (int)blockIdx.x >= grp.tile_start[p + 1]) ++p;
   const GemmArgs& g = grp.g[p];
   const int local = blockIdx.x - grp.tile_start[p];
-  const int ntx = (g.N + 31) / 32;
-  gemm_tile<AMODE, BMODE, NW, BF>(g, local % ntx, local / ntx, (g.M + 31) / 32);
+  const int ntx = (g.N + 31) / 32, nty = (g.M + 31) / 32;
+  int bx = local % ntx, by = local / ntx;
+  if (g.xcd_map && (grp.tile_start[p] & 7) == 0) xcd_tile(local, ntx, nty, bx, by);
+  gemm_tile<AMODE, BMODE, NW, BF>(g, bx, by, nty);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -841,16 +882,6 @@ __device__ __forceinline__ void gemm_lds_tile(const GemmArgs& g, const int bx, c
         c1[e] += t1;
         c2[e] += t2;
       }
-      if (g.epi == EPI_BIAS_RELU_BNX && gm2[pass] < g.M) {
-        float* crow = g.C + (size_t)gm2[pass] * g.ldc;
-        if (gn + 3 < g.N && ((g.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(crow) & 15) == 0)) {
-          *reinterpret_cast<float4*>(crow + gn) = make_float4(val[pass][0], val[pass][1], val[pass][2], val[pass][3]);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (gn + e < g.N) crow[gn + e] = val[pass][e];
-        }
-      }
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -878,7 +909,21 @@ __device__ __forceinline__ void gemm_lds_tile(const GemmArgs& g, const int bx, c
     }
     __syncthreads();
     XcView xc{g.xc_gran, g.xc_ctrl, g.xc_err, g.xc_rt_max};
-    xc_exchange<512, 64>(xc, bx, by, n_row_tiles, xtag, mine, sbuf, tot);
+    xc_exchange<512, 64>(xc, bx, by, g.Bstat < 0 ? 0 : n_row_tiles, xtag, mine, sbuf, tot, [&]() {
+      if (g.epi != EPI_BIAS_RELU_BNX) return;
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        if (gm2[pass] >= g.M) continue;
+        float* crow = g.C + (size_t)gm2[pass] * g.ldc;
+        if (gn + 3 < g.N && ((g.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(crow) & 15) == 0)) {
+          *reinterpret_cast<float4*>(crow + gn) = make_float4(val[pass][0], val[pass][1], val[pass][2], val[pass][3]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (gn + e < g.N) crow[gn + e] = val[pass][e];
+        }
+      }
+    });
     if (tid < TS) bnx_column(g, by, n0 + tid, tid, TS, tot, colp);
     __syncthreads();
     bnx_finish<2>(g, step, gm2, gn, val, av, colp, TS, c4);
@@ -941,7 +986,9 @@ __device__ __forceinline__ void gemm_lds_tile(const GemmArgs& g, const int bx, c
 
 template <int AMODE, int BMODE, bool BF = false, int BK = kLdsBKMax, bool X = false>
 __global__ __launch_bounds__(512) void gemm_lds_kernel(GemmArgs g) {
-  gemm_lds_tile<AMODE, BMODE, BF, BK, X>(g, blockIdx.x, blockIdx.y, gridDim.y);
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (g.xcd_map) xcd_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x, gridDim.y, bx, by);
+  gemm_lds_tile<AMODE, BMODE, BF, BK, X>(g, bx, by, gridDim.y);
 }
 
 // The grouped launch with 64x64 LDS tiles: the weight-gradient GEMMs read both operands k-major (lin[k][i], dz[k][j]), which
@@ -953,8 +1000,10 @@ __global__ __launch_bounds__(512) void gemm_lds_grouped_kernel(GemmGroup grp) {
   while (p + 1 < grp.n && (int)blockIdx.x >= grp.tile_start[p + 1]) ++p;
   const GemmArgs& g = grp.g[p];
   const int local = blockIdx.x - grp.tile_start[p];
-  const int ntx = (g.N + 63) / 64;
-  gemm_lds_tile<AMODE, BMODE, BF, kLdsBKMax>(g, local % ntx, local / ntx, (g.M + 63) / 64);
+  const int ntx = (g.N + 63) / 64, nty = (g.M + 63) / 64;
+  int bx = local % ntx, by = local / ntx;
+  if (g.xcd_map && (grp.tile_start[p] & 7) == 0) xcd_tile(local, ntx, nty, bx, by);
+  gemm_lds_tile<AMODE, BMODE, BF, kLdsBKMax>(g, bx, by, nty);
 }
 
 // launches up to kMaxGroup weight-gradient style GEMMs (AMODE 1, BMODE 1) as one grid
@@ -1004,6 +1053,7 @@ static int launch_gemm_group_tn(const GemmArgs* gs, int n, hipStream_t st) {
   return LIPASR_OK;
 }
 
+static int g_xcd_map = 1;    // lipasr_debug_gemm_mode bit 4 clears it: blockIdx -> tile as it comes (A/B knob)
 static int g_gemm_mode = 0;  // 0 auto, 1 split-K kernel only, 2 LDS kernel wherever it is legal (profiling knob)
 static int g_split_dw0 = 0;  // lipasr_debug_gemm_mode bit 2: the first layer's weight gradient as its own launch
 
@@ -1173,6 +1223,7 @@ static GemmArgs gemm_args(const float* A, int lda, const float* B, int ldb, floa
   GemmArgs g;
   memset(&g, 0, sizeof(g));
   g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.epi = epi;
+  g.xcd_map = g_xcd_map;
   return g;
 }
 
@@ -1490,6 +1541,7 @@ int lipasr_debug_gemm_mode(int mode) {
   g_gemm_mode = mode & 3;
   g_split_dw0 = (mode >> 2) & 1;
   g_group_lds = ((mode >> 3) & 1) ? 0 : 1;
+  g_xcd_map = ((mode >> 4) & 1) ? 0 : 1;
   return LIPASR_OK;
 }
 
@@ -1786,7 +1838,10 @@ static int train_fwd_bwd_impl(lipasr_mlp_t m, const float* params, float* bnstat
     g.part = part;
     if (bnx) {
       g.xc_gran = m->xc_gran + m->xc_gran_off[0][l]; g.xc_ctrl = m->xc_ctrl + m->xc_ctrl_off[0][l]; g.xc_err = m->xc_err; g.xc_rt_max = m->xc_rt_max;
-      g.Bstat = bstat;
+      // LIPASR_XC_NOWAIT=1 (timing probe only, results are WRONG): the exchange epilogue without its wait and sweep, to see what the
+      // exchange instances cost apart from the exchange
+      static const bool xc_nowait = getenv("LIPASR_XC_NOWAIT") != nullptr;
+      g.Bstat = xc_nowait ? -bstat : bstat;
       g.h_out = ws + L.offH;
       g.gamma = params + L.offg; g.beta = params + L.offbe;
       g.mmean_w = bnstate + L.offmm; g.mvar_w = bnstate + L.offmv; g.save_w = ws + L.offMean;
@@ -1859,7 +1914,7 @@ static int train_fwd_bwd_impl(lipasr_mlp_t m, const float* params, float* bnstat
     if (bnx) {
       gx.xc_gran = m->xc_gran + m->xc_gran_off[1][l - 1]; gx.xc_ctrl = m->xc_ctrl + m->xc_ctrl_off[1][l - 1]; gx.xc_err = m->xc_err;
       gx.xc_rt_max = m->xc_rt_max;
-      gx.Bstat = bstat; gx.grad_scale = sa.grad_scale;
+      gx.Bstat = getenv("LIPASR_XC_NOWAIT") ? -bstat : bstat; gx.grad_scale = sa.grad_scale;
       gx.gamma = params + P.offg;
       gx.dgamma = grads + P.offg; gx.dbeta = grads + P.offbe;
     }

@@ -178,10 +178,12 @@ def run_config(opt, pool, batch, rank, world, device, steps, warmup, profile):
     # same seed on every rank: replicas start identical
     model = get_model(max_batch=batch, seed=0, compute_dtype="bfloat16" if opt.get("bf16") else "float32")
     model.compile(optimizer="adam", loss=CategoricalCrossentropy(), metrics=["accuracy"])
-    # A2 "affine, precomputed": StandardScaler fitted once on MFCCs of the pool
+    # A2 "affine, precomputed": StandardScaler fitted once on the MFCCs of the WHOLE resident pool, as the reference fits it on its
+    # whole dataset (train_constraints.py:28-35: fit_transform over train + dev + test) -- until round 4 a four-batch shortcut
     ex = MfccExtractor(16000, 16000, batch, device)
-    feats = torch.cat([ex(waves[i * batch:(i + 1) * batch]) for i in range(min(4, n_batches))])
+    feats = torch.cat([ex(waves[i * batch:(i + 1) * batch]) for i in range(min(int(os.environ.get("LIPASR_SCALER_BATCHES", "1000000")), n_batches))])
     sc = StandardScaler().fit(feats)
+    del feats
     dp = DataParallel()
     comm = dp.probe(device)
     if world > 1:

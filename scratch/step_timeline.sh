@@ -7,12 +7,14 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 out=$R/gpurun_out/tl_$tag
 rm -rf $out
-rocprofv3 --kernel-trace --output-format csv -d $out -o p -- python3 $R/bench.py --pre-extracted --steps 40 --warmup 10 --skip-cpu-baseline --skip-other-configs --skip-b512 > $R/gpurun_out/tl_$tag.log 2>&1
+PRE=--pre-extracted
+if [ "$TL_CFG3" = "1" ]; then PRE=; fi   # TL_CFG3=1: the headline configuration; the extraction stream's kernels are left out of the listing
+rocprofv3 --kernel-trace --output-format csv -d $out -o p -- python3 $R/bench.py $PRE --steps 40 --warmup 10 --skip-cpu-baseline --skip-other-configs --skip-b512 > $R/gpurun_out/tl_$tag.log 2>&1
 f=$(find $out -name "*kernel_trace.csv" | head -1)
 python3 - "$f" > $R/gpurun_out/tl_$tag.txt <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-rows = [r for r in rows if "lipasr" in r["Kernel_Name"]]
+rows = [r for r in rows if "lipasr" in r["Kernel_Name"] and not any(k in r["Kernel_Name"] for k in ("resample", "stft", "dct_kernel", "flag_", "mfcc"))]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # steps are delimited by adam_nonneg_kernel; take the median-length step among the last 20
 idx = [i for i, r in enumerate(rows) if "adam_nonneg" in r["Kernel_Name"]]
