@@ -88,7 +88,13 @@ struct GemmArgs {
   // 0: exact fp32 (v_mfma_f32_32x32x2_f32).  1: operands rounded to bf16 (RNE) at the MFMA, fp32 accumulate
   // (v_mfma_f32_32x32x16_bf16): BASELINE config 2's arithmetic; memory stays fp32.
   int bf16;
+  const unsigned* sa_dyn;  // arithmetic mode 2: the operand's largest magnitude (float bits, written by its producer's epilogue): the
+  const unsigned* sb_dyn;  // scale is derived from it at run time (gradients: their size is not known beforehand); else sa / sb
+  unsigned* amax_out;      // EPI_DH_BNX: max |dz| of this launch is folded into this word (atomic max of float bits)
+  unsigned* amax_zero;     // forward launches: workgroup (0, 0) clears this word (the backward pass of the same step fills it)
+  float sa, sb;       // arithmetic mode 2: powers of two that bring op(A) and B into fp16's range before the split (the accumulator is divided by sa sb)
   int lds_min_tiles;  // host side only: 64x64 tiles from which launch_gemm takes the LDS-tiled kernel (0 = the default)
+  int ring;           // host side / grouped launch: this problem takes the LDS-DMA ring tile (mode 2, ring_legal)
   int xcd_map;        // 1: workgroup -> tile by xcd_tile() (a compact patch of the tile grid per XCD); 0: blockIdx as it comes
   // EPI_BIAS_RELU_BNX / EPI_DH_BNX (the exchange epilogue)
   unsigned long long* xc_gran;  // [32-column block][xc_rt_max][128] {tag, value}
@@ -111,6 +117,62 @@ __device__ __forceinline__ bf16x8 to_bf16x8(const float (&v)[8]) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) o[j] = (__bf16)v[j];
   return o;
+}
+
+// Arithmetic mode 2 (round 5): fp32-accurate products on the fp16 matrix instruction.  Each operand value x (scaled by a power of two
+// that keeps it inside fp16's range) is split into two fp16 planes, hi = RNE(x) and lo = RNE(x - hi) (v_fma_mix: the subtraction
+// reads hi as fp16), and a product is hi hi + hi lo + lo hi accumulated in fp32: products of fp16 numbers are exact in fp32, what
+// is lost is the 2^-22 of the two-plane representation and the lo lo term -- the technique of the resampler and the block-DFT
+// STFT (mfcc.hip, stft_bdft.hip), with three v_mfma_f32_32x32x16_f16 of 32 cycles per 16-deep chunk in place of eight
+// v_mfma_f32_32x32x2_f32 of 64.  The low plane is ONE asm statement ending in s_nop 1 (a vector-ALU result needs two wait states
+// before a matrix instruction reads it, and the hazard recogniser does not look inside inline asm).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split8(const float (&x)[8], const float scale, f16x8& hi, f16x8& lo) {
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = x[i] * scale;
+  unsigned h[4], l[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) h[i] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2v){v[2 * i], v[2 * i + 1]}, f16x2v));
+  asm("v_fma_mixlo_f16 %0, %4, 1.0, -%12 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixlo_f16 %1, %6, 1.0, -%13 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixlo_f16 %2, %8, 1.0, -%14 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixlo_f16 %3, %10, 1.0, -%15 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %0, %5, 1.0, -%12 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %1, %7, 1.0, -%13 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %2, %9, 1.0, -%14 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %3, %11, 1.0, -%15 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+      "s_nop 1"
+      : "=&v"(l[0]), "=&v"(l[1]), "=&v"(l[2]), "=&v"(l[3])
+      : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(h[0]), "v"(h[1]), "v"(h[2]), "v"(h[3]));
+  hi = __builtin_bit_cast(f16x8, make_uint4(h[0], h[1], h[2], h[3]));
+  lo = __builtin_bit_cast(f16x8, make_uint4(l[0], l[1], l[2], l[3]));
+}
+// mode 2, operands whose size is not known beforehand (gradients): the producer's epilogue leaves max |x| as float bits; the
+// scale 2^(14 - e) with max = f 2^e, f in [0.5, 1), puts the largest value in [2^13, 2^14) -- a factor 4 under fp16's 65504
+__device__ __forceinline__ float scale_from_amax(const unsigned* p, const float fallback) {
+  if (!p) return fallback;
+  const float a = __uint_as_float(*p);
+  if (!(a > 0.0f) || !(a < INFINITY)) return 1.0f;  // all zero, or NaN / inf (which then propagate as they should)
+  int e = 0;
+  (void)frexpf(a, &e);
+  return ldexpf(1.0f, 14 - e);
+}
+__device__ __forceinline__ void amax_publish(unsigned* out, float m) {
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));  // (non-negative floats order like their bits; NaN is the largest)
+}
+// one 16-deep chunk: acc += a b on three fp16 matrix instructions
+__device__ __forceinline__ f32x16 mfma_split(const float (&a)[8], const float (&b)[8], const float sa, const float sb, f32x16 acc) {
+  f16x8 ah, al, bh, bl;
+  split8(a, sa, ah, al);
+  split8(b, sb, bh, bl);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+  return acc;
 }
 
 // AMODE/BMODE 0: K contiguous in memory (operand(i,k) = P[i*ld + k]); 1: K strided (P[k*ld + i]).
@@ -324,6 +386,7 @@ __device__ __forceinline__ void bnx_finish(const GemmArgs& g, const int step, co
     }
   }
   const float invB = 1.0f / (float)g.Bstat;
+  float omax = 0.0f;  // backward: max |dz| of this thread (arithmetic mode 2 scales the consumers' operand by it)
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     if (gm[r] >= g.M) continue;
@@ -339,6 +402,7 @@ __device__ __forceinline__ void bnx_finish(const GemmArgs& g, const int step, co
         const float xh = (av[r][e] - mean[e]) * rstd[e];
         const float d = ga[e] * rstd[e] * (val[r][e] - p0[e] * invB - xh * p1[e] * invB);
         o[e] = av[r][e] > 0.0f ? d : 0.0f;
+        if (gn + e < g.N) omax = fmaxf(omax, fabsf(o[e]));
       }
     }
     float* crow = (fwd ? g.h_out : g.C) + (size_t)gm[r] * g.ldc;
@@ -350,6 +414,7 @@ __device__ __forceinline__ void bnx_finish(const GemmArgs& g, const int step, co
         if (gn + e < g.N) crow[gn + e] = o[e];
     }
   }
+  if (!fwd && g.amax_out) amax_publish(g.amax_out, omax);  // (every thread of the wavefront reaches this point)
 }
 
 // one column of the block after the exchange: forward -> [mean | rstd] (+ moving statistics and the saved statistics, by
@@ -435,7 +500,7 @@ __device__ __forceinline__ void xcd_tile(const int L, const int ntx, const int n
 
 // One workgroup = one 32x32 output tile; its NW wavefronts (4, or 16 for small outputs with a long K) split K
 // in 16-deep chunks, round-robin.  Operand fragments go global/L2 -> VGPR directly, one chunk ahead of the MFMAs.
-template <int AMODE, int BMODE, int NW, bool BF, bool X = false>  // X: the exchange epilogue (its own instances: with it as a run-time
+template <int AMODE, int BMODE, int NW, int BF, bool X = false>  // X: the exchange epilogue (its own instances: with it as a run-time
 __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const int by, const int n_row_tiles) {  // branch every GEMM grew from 50-66 to 83 VGPRs)
   constexpr int TS = 32;
   constexpr int TPR = 8;                       // threads per output row (one float4 each)
@@ -455,6 +520,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
 
   unsigned xtag = 0;
   if constexpr (X) xtag = xc_tag<32>(XcView{g.xc_gran, g.xc_ctrl, g.xc_err, g.xc_rt_max}, bx);
+  float rsa = 1.0f, rsb = 1.0f;
+  if (BF == 2) { rsa = scale_from_amax(g.sa_dyn, g.sa); rsb = scale_from_amax(g.sb_dyn, g.sb); }
+  if (g.amax_zero && bx == 0 && by == 0 && tid == 0) *g.amax_zero = 0u;
   f32x16 acc;
 #pragma unroll
   for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
@@ -473,9 +541,11 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
       load_frag<AMODE>(g.A, g.lda, ai, cn * 16 + 8 * h, g.K, vecA, a1, aones);
       load_frag<BMODE>(g.B, g.ldb, bj, cn * 16 + 8 * h, g.K, vecB, b1);
     }
-    if (BF) {
+    if (BF == 1) {
       // the chunk's 16 k values are exactly one 32x32x16 bf16 fragment per operand (same lane map as the loads)
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(to_bf16x8(a0), to_bf16x8(b0), acc, 0, 0, 0);
+    } else if (BF == 2) {
+      acc = mfma_split(a0, b0, rsa, rsb, acc);
     } else {
 #pragma unroll
       for (int q = 0; q < 8; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q], b0[q], acc, 0, 0, 0);
@@ -483,6 +553,11 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
 #pragma unroll
     for (int q = 0; q < 8; ++q) { a0[q] = a1[q]; b0[q] = b1[q]; }
     c = cn;
+  }
+  if (BF == 2) {
+    const float un = 1.0f / (rsa * rsb);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] *= un;
   }
   BnxPre xpre;
   if constexpr (X && NW == 4) bnx_prefetch(g, m0 + (tid >> 3), n0 + (tid & 7) * 4, xpre);
@@ -678,7 +753,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
   }
 }
 
-template <int AMODE, int BMODE, int NW, bool BF = false, bool X = false>  // BF: operands rounded to bf16 at the MFMA (compile-time: a
+template <int AMODE, int BMODE, int NW, int BF = 0, bool X = false>  // BF: operands rounded to bf16 at the MFMA (compile-time: a
 __global__ __launch_bounds__(64 * NW) void gemm_f32_kernel(GemmArgs g) {  // run-time switch cost the fp32 path 6 %)
   int bx = blockIdx.x, by = blockIdx.y;
   if (g.xcd_map) xcd_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x, gridDim.y, bx, by);
@@ -695,7 +770,7 @@ struct GemmGroup {
   GemmArgs g[kMaxGroup];
 };
 
-template <int AMODE, int BMODE, int NW, bool BF = false>
+template <int AMODE, int BMODE, int NW, int BF = 0>
 __global__ __launch_bounds__(64 * NW) void gemm_f32_grouped_kernel(GemmGroup grp) {
   int p = 0;
   while (p + 1 < grp.n && (int)blockIdx.x >= grp.tile_start[p + 1]) ++p;
@@ -773,82 +848,17 @@ constexpr size_t lds_gemm_bytes(int bk) {
   return ((size_t)(2 * 2 * bk * kLdsLD > 2 * 64 * 64 ? 2 * 2 * bk * kLdsLD : 2 * 64 * 64) + 8 * 16 * 8) * sizeof(float);
 }
 
-template <int AMODE, int BMODE, bool BF, int BK, bool X = false>  // BK: k rows per LDS tile (32 or 64); X: the exchange epilogue
-__device__ __forceinline__ void gemm_lds_tile(const GemmArgs& g, const int bx, const int by, const int n_row_tiles) {
+// The epilogue of a 64 x 64 tile held as eight 32 x 32 accumulators (wavefront = (K half, quadrant)): the two K halves meet in LDS
+// (`red`: the first 32 KB of the workgroup's dynamic LDS, free by now), then bias / ReLU / statistics / the exchange epilogue /
+// stores.  Shared by the LDS-tiled kernel and the LDS-DMA ring kernel.
+template <bool X>
+__device__ __forceinline__ void lds_tile_epilogue(const GemmArgs& g, const f32x16& acc, float* lds, float* stat, const int bx, const int by,
+                                                  const int n_row_tiles, const unsigned xtag) {
   constexpr int TS = 64;
-  constexpr int NF = BK / kLdsBK;  // 32-row fetches per operand and tile
-  extern __shared__ __attribute__((aligned(16))) float lds[];  // [buf][A|B][BK][68]; reused as [2][64][64]; then stat
-  float* stat = lds + (2 * 2 * BK * kLdsLD > 2 * 64 * 64 ? 2 * 2 * BK * kLdsLD : 2 * 64 * 64);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int kh = wave >> 2, wi = (wave >> 1) & 1, wj = wave & 1;
   const int m0 = by * TS, n0 = bx * TS;
-  const int m_real = g.ones_row ? g.M - 1 : g.M;
-  const int nst = (g.K + BK - 1) / BK;
-  const bool ones = g.ones_row != 0;
-  unsigned xtag = 0;
-  if constexpr (X) xtag = xc_tag<64>(XcView{g.xc_gran, g.xc_ctrl, g.xc_err, g.xc_rt_max}, bx);
-  f32x16 acc;
-#pragma unroll
-  for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
-  // Operand tiles travel global/L2 -> registers -> LDS.  A k-step's MFMAs take 0.25 us per 32 k rows, an L2 round trip
-  // more: with the fetch of tile t+1 issued at the top of step t and stored at its bottom, every step waited for memory
-  // (28 steps x ~0.8 us on the 880-deep layer-1 GEMMs).  The ring below keeps TWO tiles in flight (tile t+2 is
-  // requested at the top of step t and stored at the bottom of step t+1): 29.1 -> 26.3 us on that GEMM.
-  struct Tile { float4 a[NF], b[NF]; };
-  auto fetch = [&](Tile& tl, const int t) {
-#pragma unroll
-    for (int f = 0; f < NF; ++f) {
-      tl.a[f] = tile_fetch<AMODE>(g.A, g.lda, m0, m_real, t * BK + f * kLdsBK, g.K, ones, g.M - 1, tid);
-      tl.b[f] = tile_fetch<BMODE>(g.B, g.ldb, n0, g.N, t * BK + f * kLdsBK, g.K, false, 0, tid);
-    }
-  };
-  auto park = [&](const Tile& tl, const int t) {
-    float* An = lds + (t & 1) * 2 * BK * kLdsLD;
-#pragma unroll
-    for (int f = 0; f < NF; ++f) {
-      tile_store<AMODE>(An + f * kLdsBK * kLdsLD, tid, tl.a[f]);
-      tile_store<BMODE>(An + BK * kLdsLD + f * kLdsBK * kLdsLD, tid, tl.b[f]);
-    }
-  };
-  Tile t0, t1;
-  fetch(t0, 0);
-  if (nst > 1) fetch(t1, 1);
-  park(t0, 0);
-  __syncthreads();
-  // one k-step: request tile t+2 into the free register slot, multiply tile t out of LDS, park tile t+1 (requested one
-  // step ago) in the other LDS buffer
-  auto kstep = [&](const int t, Tile& free_slot, const Tile& ready) {
-    if (t + 2 < nst) fetch(free_slot, t + 2);
-    // this wavefront's K half of the tile: BK/2 rows from (BK/2) kh, in groups of 16.  fp32: lane half h takes
-    // k = h + 2 s of a group (one 32x32x2 per s); bf16: k = 8 h + s (one 32x32x16 per group)
-    constexpr int kstr = BF ? kLdsLD : 2 * kLdsLD;
-    const int koff = BF ? 8 * h : h;
-    const float* base = lds + (t & 1) * 2 * BK * kLdsLD + ((BK / 2) * kh + koff) * kLdsLD + r;
-#pragma unroll
-    for (int q = 0; q < BK / 32; ++q) {
-      const float* As = base + 16 * q * kLdsLD + 32 * wi;
-      const float* Bs = base + BK * kLdsLD + 16 * q * kLdsLD + 32 * wj;
-      float av[8], bv[8];
-#pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        av[s] = As[s * kstr];
-        bv[s] = Bs[s * kstr];
-      }
-      if (BF) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(to_bf16x8(av), to_bf16x8(bv), acc, 0, 0, 0);
-      } else {
-#pragma unroll
-        for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc, 0, 0, 0);
-      }
-    }
-    if (t + 1 < nst) park(ready, t + 1);
-    __syncthreads();
-  };
-  for (int t = 0; t < nst; t += 2) {
-    kstep(t, t0, t1);                    // even step: slot 0 is free (tile t is in LDS), slot 1 holds tile t+1
-    if (t + 1 < nst) kstep(t + 1, t1, t0);  // odd step: the roles swap
-  }
   BnxPre xpre[2];
   if constexpr (X) {
     bnx_prefetch(g, m0 + (tid >> 4), n0 + (tid & 15) * 4, xpre[0]);
@@ -984,7 +994,223 @@ __device__ __forceinline__ void gemm_lds_tile(const GemmArgs& g, const int bx, c
   }
 }
 
-template <int AMODE, int BMODE, bool BF = false, int BK = kLdsBKMax, bool X = false>
+
+template <int AMODE, int BMODE, int BF, int BK, bool X = false>  // BK: k rows per LDS tile (32 or 64); X: the exchange epilogue
+__device__ __forceinline__ void gemm_lds_tile(const GemmArgs& g, const int bx, const int by, const int n_row_tiles) {
+  constexpr int TS = 64;
+  constexpr int NF = BK / kLdsBK;  // 32-row fetches per operand and tile
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [buf][A|B][BK][68]; reused as [2][64][64]; then stat
+  float* stat = lds + (2 * 2 * BK * kLdsLD > 2 * 64 * 64 ? 2 * 2 * BK * kLdsLD : 2 * 64 * 64);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int kh = wave >> 2, wi = (wave >> 1) & 1, wj = wave & 1;
+  const int m0 = by * TS, n0 = bx * TS;
+  const int m_real = g.ones_row ? g.M - 1 : g.M;
+  const int nst = (g.K + BK - 1) / BK;
+  const bool ones = g.ones_row != 0;
+  unsigned xtag = 0;
+  if constexpr (X) xtag = xc_tag<64>(XcView{g.xc_gran, g.xc_ctrl, g.xc_err, g.xc_rt_max}, bx);
+  float rsa = 1.0f, rsb = 1.0f;
+  if (BF == 2) { rsa = scale_from_amax(g.sa_dyn, g.sa); rsb = scale_from_amax(g.sb_dyn, g.sb); }
+  if (g.amax_zero && bx == 0 && by == 0 && tid == 0) *g.amax_zero = 0u;
+  f32x16 acc;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+  // Operand tiles travel global/L2 -> registers -> LDS.  A k-step's MFMAs take 0.25 us per 32 k rows, an L2 round trip
+  // more: with the fetch of tile t+1 issued at the top of step t and stored at its bottom, every step waited for memory
+  // (28 steps x ~0.8 us on the 880-deep layer-1 GEMMs).  The ring below keeps TWO tiles in flight (tile t+2 is
+  // requested at the top of step t and stored at the bottom of step t+1): 29.1 -> 26.3 us on that GEMM.
+  struct Tile { float4 a[NF], b[NF]; };
+  auto fetch = [&](Tile& tl, const int t) {
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      tl.a[f] = tile_fetch<AMODE>(g.A, g.lda, m0, m_real, t * BK + f * kLdsBK, g.K, ones, g.M - 1, tid);
+      tl.b[f] = tile_fetch<BMODE>(g.B, g.ldb, n0, g.N, t * BK + f * kLdsBK, g.K, false, 0, tid);
+    }
+  };
+  auto park = [&](const Tile& tl, const int t) {
+    float* An = lds + (t & 1) * 2 * BK * kLdsLD;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      tile_store<AMODE>(An + f * kLdsBK * kLdsLD, tid, tl.a[f]);
+      tile_store<BMODE>(An + BK * kLdsLD + f * kLdsBK * kLdsLD, tid, tl.b[f]);
+    }
+  };
+  Tile t0, t1;
+  fetch(t0, 0);
+  if (nst > 1) fetch(t1, 1);
+  park(t0, 0);
+  __syncthreads();
+  // one k-step: request tile t+2 into the free register slot, multiply tile t out of LDS, park tile t+1 (requested one
+  // step ago) in the other LDS buffer
+  auto kstep = [&](const int t, Tile& free_slot, const Tile& ready) {
+    if (t + 2 < nst) fetch(free_slot, t + 2);
+    // this wavefront's K half of the tile: BK/2 rows from (BK/2) kh, in groups of 16.  fp32: lane half h takes
+    // k = h + 2 s of a group (one 32x32x2 per s); bf16: k = 8 h + s (one 32x32x16 per group)
+    constexpr int kstr = BF ? kLdsLD : 2 * kLdsLD;  // (modes 1 and 2 share the 32x32x16 lane map)
+    const int koff = BF ? 8 * h : h;
+    const float* base = lds + (t & 1) * 2 * BK * kLdsLD + ((BK / 2) * kh + koff) * kLdsLD + r;
+#pragma unroll
+    for (int q = 0; q < BK / 32; ++q) {
+      const float* As = base + 16 * q * kLdsLD + 32 * wi;
+      const float* Bs = base + BK * kLdsLD + 16 * q * kLdsLD + 32 * wj;
+      float av[8], bv[8];
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        av[s] = As[s * kstr];
+        bv[s] = Bs[s * kstr];
+      }
+      if (BF == 1) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(to_bf16x8(av), to_bf16x8(bv), acc, 0, 0, 0);
+      } else if (BF == 2) {
+        acc = mfma_split(av, bv, rsa, rsb, acc);
+      } else {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc, 0, 0, 0);
+      }
+    }
+    if (t + 1 < nst) park(ready, t + 1);
+    __syncthreads();
+  };
+  for (int t = 0; t < nst; t += 2) {
+    kstep(t, t0, t1);                    // even step: slot 0 is free (tile t is in LDS), slot 1 holds tile t+1
+    if (t + 1 < nst) kstep(t + 1, t1, t0);  // odd step: the roles swap
+  }
+  if (BF == 2) {
+    const float un = 1.0f / (rsa * rsb);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] *= un;
+  }
+  lds_tile_epilogue<X>(g, acc, lds, stat, bx, by, n_row_tiles, xtag);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// The LDS-DMA ring kernel (round 5; arithmetic mode 2 only).  Same 64 x 64 tile, same eight wavefronts (K half, quadrant) and the
+// same epilogue as gemm_lds_tile -- what changes is how the operand tiles reach LDS.  With the products on the fp16 matrix
+// instruction a 32-deep k-step is ~200 cycles of arithmetic per wavefront, and the register-staged pipeline (global -> VGPR ->
+// ds_write, two tiles in flight, 8 + 8 ds_read_b32 per operand group) was bound by the memory round trip per step: the grouped
+// weight-gradient launch took 77 us on 128 CUs for ~10 us of arithmetic.  Here every wavefront issues two
+// `global_load_lds_dwordx4` per k-step (1 KB each, straight into the ring slot: no staging registers, no LDS store instructions),
+// FOUR k-steps live in the 64 KB ring and three are in flight behind the one being multiplied; one workgroup barrier per k-step.
+//   * operand stored k-major in memory (P[k ld + i]: both operands of the weight-gradient GEMMs, the kernels in the forward
+//     pass): the slot holds [32 k][64 i], one DMA instruction = 4 k rows; fragment reads are unit-stride ds_read_b32.
+//   * operand stored K-contiguous (P[i ld + k]: activations, dz, the kernels in the dX GEMMs): the slot holds [64 i][32 k] with the
+//     eight 16-byte chunks of a row XOR-swizzled by (i >> 1) & 7 -- an LDS-DMA instruction writes lane l's 16 bytes at l x 16, so
+//     the swizzle is applied to the ADDRESS each lane fetches from; a fragment (8 consecutive k of row i) is two ds_read_b128,
+//     conflict-free in the hardware's 16-lane groups (MI355X_MICROARCH.md, LDS).
+// The DMA instructions are inline asm: the compiler waits for vmcnt(0) in front of every LDS read that follows a
+// __builtin_amdgcn_global_load_lds (it cannot tell the slots apart), which would take the three k-steps in flight back to none;
+// the waits are counted by hand (two DMA instructions per wavefront and k-step, completed in order).
+// Legal when K is a multiple of 32, both leading dimensions are multiples of 4, both bases 16-byte aligned and a k-major
+// operand's extent is a multiple of 4 (ring_legal); anything else takes gemm_lds_tile / gemm_tile, which handle every shape.
+// ---------------------------------------------------------------------------------------------
+constexpr int kRingStages = 4;
+constexpr int kRingTile = 64 * 32;  // floats of one operand tile of one k-step (8 KB)
+constexpr size_t ring_gemm_bytes() { return (size_t)(kRingStages * 2 * kRingTile + 8 * 16 * 8) * sizeof(float); }
+
+__device__ __forceinline__ void dma16(const float* gsrc, const unsigned lds_byte_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_byte_addr)
+               : "memory");
+}
+
+// this lane's source address of operand tile rows/columns i0 .. i0 + 63 at k = 0 (advance by ring_step per k-step)
+template <int MODE>
+__device__ __forceinline__ const float* ring_src(const float* P, const int ld, const int i0, const int i_real, const int wave, const int lane) {
+  if (MODE == 1) {
+    const int k = 4 * wave + (lane >> 4), i = min(i0 + (lane & 15) * 4, i_real - 4);
+    return P + (size_t)k * ld + i;
+  }
+  const int il = 8 * wave + (lane >> 3), c = (lane & 7) ^ ((il >> 1) & 7);
+  return P + (size_t)min(i0 + il, i_real - 1) * ld + 4 * c;
+}
+template <int MODE>
+__device__ __forceinline__ size_t ring_step(const int ld) { return MODE == 1 ? (size_t)32 * ld : (size_t)32; }
+
+// the 8 consecutive k (16 kh + 8 hh ..) of row / column `il` of an operand tile in a ring slot
+template <int MODE>
+__device__ __forceinline__ void ring_frag(const float* __restrict__ T, const int il, const int kh, const int hh, float (&v)[8]) {
+  if (MODE == 1) {
+    const float* q = T + (16 * kh + 8 * hh) * 64 + il;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) v[s] = q[s * 64];
+  } else {
+    const int sw = (il >> 1) & 7, c0 = 4 * kh + 2 * hh;
+    const float4 lo = *reinterpret_cast<const float4*>(T + (il * 8 + (c0 ^ sw)) * 4);
+    const float4 hi = *reinterpret_cast<const float4*>(T + (il * 8 + ((c0 + 1) ^ sw)) * 4);
+    v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w;
+    v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+  }
+}
+
+template <int AMODE, int BMODE, bool X = false>
+__device__ __forceinline__ void gemm_ring_tile(const GemmArgs& g, const int bx, const int by, const int n_row_tiles) {
+  constexpr int TS = 64, S = kRingStages;
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [S][A | B][2048]; the epilogue reuses the first 32 KB; then stat
+  float* stat = lds + S * 2 * kRingTile;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, hh = lane >> 5;
+  const int kh = wave >> 2, wi = (wave >> 1) & 1, wj = wave & 1;
+  const int m0 = by * TS, n0 = bx * TS;
+  const int m_real = g.ones_row ? g.M - 1 : g.M;
+  const int nst = g.K >> 5;
+  unsigned xtag = 0;
+  if constexpr (X) xtag = xc_tag<64>(XcView{g.xc_gran, g.xc_ctrl, g.xc_err, g.xc_rt_max}, bx);
+  const float rsa = scale_from_amax(g.sa_dyn, g.sa), rsb = scale_from_amax(g.sb_dyn, g.sb);
+  if (g.amax_zero && bx == 0 && by == 0 && tid == 0) *g.amax_zero = 0u;
+  const float* pa = ring_src<AMODE>(g.A, g.lda, m0, m_real, wave, lane);
+  const float* pb = ring_src<BMODE>(g.B, g.ldb, n0, g.N, wave, lane);
+  const size_t sa_step = ring_step<AMODE>(g.lda), sb_step = ring_step<BMODE>(g.ldb);
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds) + (unsigned)wave * 1024u;  // this wavefront's 1 KB of an A tile
+  auto issue = [&](const int t) {
+    const unsigned slot = lds0 + (unsigned)(t % S) * (2u * kRingTile * 4u);
+    dma16(pa, slot);
+    dma16(pb, slot + kRingTile * 4u);
+    pa += sa_step;
+    pb += sb_step;
+  };
+  const int pre = min(S - 1, nst);
+  for (int t = 0; t < pre; ++t) issue(t);
+  // the all-ones row of op(A) (bias gradient of the weight-gradient GEMMs) does not exist in memory: it is written into the slot
+  const int il_ones = (AMODE == 1 && g.ones_row && g.M - 1 >= m0 && g.M - 1 < m0 + TS) ? g.M - 1 - m0 : -1;
+  f32x16 acc;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+  for (int t = 0; t < nst; ++t) {
+    const int ahead = min(t + S - 2, nst - 1) - t;  // k-steps requested beyond t: two DMA instructions each, completed in order
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float* At = lds + (t % S) * 2 * kRingTile;
+    if (il_ones >= 0 && lane < 4) At[(4 * wave + lane) * 64 + il_ones] = 1.0f;  // (this wavefront's own four k rows: they have landed)
+    __syncthreads();  // every wavefront's part of k-step t is in LDS, and everybody is done with the slot of k-step t - 1
+    if (t + S - 1 < nst) issue(t + S - 1);
+    float av[8], bv[8];
+    ring_frag<AMODE>(At, 32 * wi + r, kh, hh, av);
+    ring_frag<BMODE>(At + kRingTile, 32 * wj + r, kh, hh, bv);
+    acc = mfma_split(av, bv, rsa, rsb, acc);
+  }
+  {
+    const float un = 1.0f / (rsa * rsb);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] *= un;
+  }
+  __syncthreads();  // the last k-step's fragments are read: the ring becomes the epilogue's `red`
+  lds_tile_epilogue<X>(g, acc, lds, stat, bx, by, n_row_tiles, xtag);
+}
+
+template <int AMODE, int BMODE, bool X = false>
+__global__ __launch_bounds__(512) void gemm_ring_kernel(GemmArgs g) {
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (g.xcd_map) xcd_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x, gridDim.y, bx, by);
+  gemm_ring_tile<AMODE, BMODE, X>(g, bx, by, gridDim.y);
+}
+
+template <int AMODE, int BMODE, int BF = 0, int BK = kLdsBKMax, bool X = false>
 __global__ __launch_bounds__(512) void gemm_lds_kernel(GemmArgs g) {
   int bx = blockIdx.x, by = blockIdx.y;
   if (g.xcd_map) xcd_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x, gridDim.y, bx, by);
@@ -994,7 +1220,7 @@ __global__ __launch_bounds__(512) void gemm_lds_kernel(GemmArgs g) {
 // The grouped launch with 64x64 LDS tiles: the weight-gradient GEMMs read both operands k-major (lin[k][i], dz[k][j]), which
 // is exactly the LDS image, so a tile is staged by plain float4 copies and every operand element leaves L2 once per 64x64
 // tile -- half the L2 -> CU traffic of the 32x32 fragment kernel (410 MB per step at batch 1024), which is what bounded it.
-template <int AMODE, int BMODE, bool BF = false>
+template <int AMODE, int BMODE, int BF = 0>
 __global__ __launch_bounds__(512) void gemm_lds_grouped_kernel(GemmGroup grp) {
   int p = 0;
   while (p + 1 < grp.n && (int)blockIdx.x >= grp.tile_start[p + 1]) ++p;
@@ -1005,6 +1231,39 @@ __global__ __launch_bounds__(512) void gemm_lds_grouped_kernel(GemmGroup grp) {
   if (g.xcd_map && (grp.tile_start[p] & 7) == 0) xcd_tile(local, ntx, nty, bx, by);
   gemm_lds_tile<AMODE, BMODE, BF, kLdsBKMax>(g, bx, by, nty);
 }
+
+// the grouped weight-gradient launch in arithmetic mode 2: every problem that is ring_legal on the LDS-DMA ring tile, the others
+// (the 64 x 10 output layer: its extent is no multiple of 4) on the register-staged tile
+__global__ __launch_bounds__(512) void gemm_ring_grouped_kernel(GemmGroup grp) {
+  int p = 0;
+  while (p + 1 < grp.n && (int)blockIdx.x >= grp.tile_start[p + 1]) ++p;
+  const GemmArgs& g = grp.g[p];
+  const int local = blockIdx.x - grp.tile_start[p];
+  const int ntx = (g.N + 63) / 64, nty = (g.M + 63) / 64;
+  int bx = local % ntx, by = local / ntx;
+  if (g.xcd_map && (grp.tile_start[p] & 7) == 0) xcd_tile(local, ntx, nty, bx, by);
+  if (g.ring) gemm_ring_tile<1, 1>(g, bx, by, nty);
+  else gemm_lds_tile<1, 1, 2, kLdsBKMax>(g, bx, by, nty);
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+// amode / bmode: 1 = the operand is k-major in memory (P[k ld + i])
+static bool ring_legal(int amode, int bmode, const GemmArgs& g) {
+  if (g.bf16 != 2 || g.M < 64 || g.N < 64 || g.K < 32 || (g.K & 31)) return false;
+  if ((g.lda & 3) || (g.ldb & 3) || !aligned16(g.A) || !aligned16(g.B)) return false;
+  const int m_real = g.ones_row ? g.M - 1 : g.M;
+  if (amode == 1 && ((m_real & 3) || m_real < 4)) return false;
+  if (bmode == 1 && ((g.N & 3) || g.N < 4)) return false;
+  return true;
+}
+
+// arithmetic mode (GemmArgs::bf16: 0 exact fp32, 1 bf16 operands, 2 fp16 two-plane split) -> template instance
+#define LP_DISPATCH_AR(ar, M) \
+  do {                        \
+    if ((ar) == 2) { M(2) }   \
+    else if ((ar) == 1) { M(1) } \
+    else { M(0) }             \
+  } while (0)
 
 // launches up to kMaxGroup weight-gradient style GEMMs (AMODE 1, BMODE 1) as one grid
 static int g_group_lds = 1;  // lipasr_debug_gemm_mode bit 3 clears it: the grouped launch on 32x32 fragment tiles (round 2)
@@ -1030,22 +1289,34 @@ static int launch_gemm_group_tn(const GemmArgs* gs, int n, hipStream_t st) {
     }
     grp.n = k;
     grp.tile_start[k] = tiles;
-    if (lds_tiles) {
+    const int ar = gs[done].bf16;
+    bool any_ring = false;
+    if (lds_tiles && ar == 2)
+      for (int q = 0; q < k; ++q) { grp.g[q].ring = ring_legal(1, 1, grp.g[q]) ? 1 : 0; any_ring = any_ring || grp.g[q].ring; }
+    if (any_ring) {
+      static bool attr_set_dev[16] = {}; int attr_dev = 0; (void)hipGetDevice(&attr_dev); bool& attr_set = attr_set_dev[attr_dev & 15];
+      if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring_grouped_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_gemm_bytes());
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(gemm_ring_grouped_kernel, dim3(tiles), dim3(512), ring_gemm_bytes(), st, grp);
+    } else if (lds_tiles) {
       constexpr size_t lds_b = lds_gemm_bytes(kLdsBKMax);
       static bool attr_set_dev[16] = {}; int attr_dev = 0; (void)hipGetDevice(&attr_dev); bool& attr_set = attr_set_dev[attr_dev & 15];  /* per device */
       if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_lds_grouped_kernel<1, 1, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_lds_grouped_kernel<1, 1, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
+#define LP_M(AR) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_lds_grouped_kernel<1, 1, AR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
+        LP_M(0) LP_M(1) LP_M(2)
+#undef LP_M
         attr_set = true;
       }
-      if (gs[done].bf16) hipLaunchKernelGGL((gemm_lds_grouped_kernel<1, 1, true>), dim3(tiles), dim3(512), lds_b, st, grp);
-      else hipLaunchKernelGGL((gemm_lds_grouped_kernel<1, 1, false>), dim3(tiles), dim3(512), lds_b, st, grp);
+#define LP_M(AR) hipLaunchKernelGGL((gemm_lds_grouped_kernel<1, 1, AR>), dim3(tiles), dim3(512), lds_b, st, grp);
+      LP_DISPATCH_AR(ar, LP_M);
+#undef LP_M
     } else {
       const size_t lds = (size_t)(4 * 32 * 32 + 4 * 8 * 8) * sizeof(float);
-      if (gs[done].bf16) hipLaunchKernelGGL((gemm_f32_grouped_kernel<1, 1, 4, true>), dim3(tiles), dim3(256), lds, st, grp);
-      else hipLaunchKernelGGL((gemm_f32_grouped_kernel<1, 1, 4, false>), dim3(tiles), dim3(256), lds, st, grp);
+#define LP_M(AR) hipLaunchKernelGGL((gemm_f32_grouped_kernel<1, 1, 4, AR>), dim3(tiles), dim3(256), lds, st, grp);
+      LP_DISPATCH_AR(ar, LP_M);
+#undef LP_M
     }
     LP_LAUNCH_CHECK();
     done += k;
@@ -1067,7 +1338,7 @@ static bool use_lds_gemm(int M, int N, int K, int min_tiles = 0) {
   return legal && tiles >= (min_tiles > 0 ? min_tiles : kLdsMinTiles);
 }
 
-template <int AMODE, int BMODE, int NW, bool BF>
+template <int AMODE, int BMODE, int NW, int BF>
 static void launch_gemm_tb(const GemmArgs& g, hipStream_t st) {
   const dim3 grid((g.N + 31) / 32, (g.M + 31) / 32);
   const size_t lds = (size_t)(NW * 32 * 32 + 4 * 8 * 8) * sizeof(float);
@@ -1082,8 +1353,9 @@ static void launch_gemm_tb(const GemmArgs& g, hipStream_t st) {
 
 template <int AMODE, int BMODE, int NW>
 static void launch_gemm_t(const GemmArgs& g, hipStream_t st) {
-  if (g.bf16) launch_gemm_tb<AMODE, BMODE, NW, true>(g, st);
-  else launch_gemm_tb<AMODE, BMODE, NW, false>(g, st);
+#define LP_M(AR) launch_gemm_tb<AMODE, BMODE, NW, AR>(g, st);
+  LP_DISPATCH_AR(g.bf16, LP_M);
+#undef LP_M
 }
 
 static int launch_gemm(int amode, int bmode, const GemmArgs& g, hipStream_t st) {
@@ -1102,53 +1374,85 @@ static int launch_gemm(int amode, int bmode, const GemmArgs& g, hipStream_t st) 
   }
   if (g.epi == EPI_BIAS_RELU_BNX || g.epi == EPI_DH_BNX) {  // the exchange epilogue: forward (NN) or input-gradient (NT) GEMMs only
     if (amode != 0) { set_error("gemm: the exchange epilogue needs a row-major A operand"); return LIPASR_EINVAL; }
-    if (use_lds_gemm(g.M, g.N, g.K, g.lds_min_tiles)) {
+    if (use_lds_gemm(g.M, g.N, g.K, g.lds_min_tiles) && ring_legal(0, bmode, g)) {
+      const dim3 grid((g.N + 63) / 64, (g.M + 63) / 64);
+      static bool attr_set_dev[16] = {}; int attr_dev = 0; (void)hipGetDevice(&attr_dev); bool& attr_set = attr_set_dev[attr_dev & 15];
+      if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring_kernel<0, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_gemm_bytes());
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring_kernel<0, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_gemm_bytes());
+        attr_set = true;
+      }
+      if (bmode == 0) hipLaunchKernelGGL((gemm_ring_kernel<0, 0, true>), grid, dim3(512), ring_gemm_bytes(), st, g);
+      else hipLaunchKernelGGL((gemm_ring_kernel<0, 1, true>), grid, dim3(512), ring_gemm_bytes(), st, g);
+    } else if (use_lds_gemm(g.M, g.N, g.K, g.lds_min_tiles)) {
       const dim3 grid((g.N + 63) / 64, (g.M + 63) / 64);
       constexpr size_t lds_b = lds_gemm_bytes(kLdsBKMax);
       static bool attr_set_dev[16] = {}; int attr_dev = 0; (void)hipGetDevice(&attr_dev); bool& attr_set = attr_set_dev[attr_dev & 15];
       if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_lds_kernel<0, 0, false, kLdsBKMax, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_lds_kernel<0, 0, true, kLdsBKMax, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_lds_kernel<0, 1, false, kLdsBKMax, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_lds_kernel<0, 1, true, kLdsBKMax, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
+#define LP_M(AR)                                                                                                                                   \
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_lds_kernel<0, 0, AR, kLdsBKMax, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b); \
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_lds_kernel<0, 1, AR, kLdsBKMax, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
+        LP_M(0) LP_M(1) LP_M(2)
+#undef LP_M
         attr_set = true;
       }
       if (bmode == 0) {
-        if (g.bf16) hipLaunchKernelGGL((gemm_lds_kernel<0, 0, true, kLdsBKMax, true>), grid, dim3(512), lds_b, st, g);
-        else hipLaunchKernelGGL((gemm_lds_kernel<0, 0, false, kLdsBKMax, true>), grid, dim3(512), lds_b, st, g);
+#define LP_M(AR) hipLaunchKernelGGL((gemm_lds_kernel<0, 0, AR, kLdsBKMax, true>), grid, dim3(512), lds_b, st, g);
+        LP_DISPATCH_AR(g.bf16, LP_M);
+#undef LP_M
       } else {
-        if (g.bf16) hipLaunchKernelGGL((gemm_lds_kernel<0, 1, true, kLdsBKMax, true>), grid, dim3(512), lds_b, st, g);
-        else hipLaunchKernelGGL((gemm_lds_kernel<0, 1, false, kLdsBKMax, true>), grid, dim3(512), lds_b, st, g);
+#define LP_M(AR) hipLaunchKernelGGL((gemm_lds_kernel<0, 1, AR, kLdsBKMax, true>), grid, dim3(512), lds_b, st, g);
+        LP_DISPATCH_AR(g.bf16, LP_M);
+#undef LP_M
       }
     } else {
       const dim3 grid((g.N + 31) / 32, (g.M + 31) / 32);
       const size_t lds = (size_t)(4 * 32 * 32 + 4 * 8 * 8) * sizeof(float);
       if (bmode == 0) {
-        if (g.bf16) hipLaunchKernelGGL((gemm_f32_kernel<0, 0, 4, true, true>), grid, dim3(256), lds, st, g);
-        else hipLaunchKernelGGL((gemm_f32_kernel<0, 0, 4, false, true>), grid, dim3(256), lds, st, g);
+#define LP_M(AR) hipLaunchKernelGGL((gemm_f32_kernel<0, 0, 4, AR, true>), grid, dim3(256), lds, st, g);
+        LP_DISPATCH_AR(g.bf16, LP_M);
+#undef LP_M
       } else {
-        if (g.bf16) hipLaunchKernelGGL((gemm_f32_kernel<0, 1, 4, true, true>), grid, dim3(256), lds, st, g);
-        else hipLaunchKernelGGL((gemm_f32_kernel<0, 1, 4, false, true>), grid, dim3(256), lds, st, g);
+#define LP_M(AR) hipLaunchKernelGGL((gemm_f32_kernel<0, 1, 4, AR, true>), grid, dim3(256), lds, st, g);
+        LP_DISPATCH_AR(g.bf16, LP_M);
+#undef LP_M
       }
     }
+    LP_LAUNCH_CHECK();
+    return LIPASR_OK;
+  }
+  if (use_lds_gemm(g.M, g.N, g.K, g.lds_min_tiles) && ring_legal(amode, bmode, g)) {
+    const dim3 grid((g.N + 63) / 64, (g.M + 63) / 64);
+#define LP_RING(A_, B_)                                                                                                                 \
+  {                                                                                                                                     \
+    static bool attr_set_dev[16] = {}; int attr_dev = 0; (void)hipGetDevice(&attr_dev); bool& attr_set = attr_set_dev[attr_dev & 15];   \
+    if (!attr_set) {                                                                                                                    \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring_kernel<A_, B_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_gemm_bytes()); \
+      attr_set = true;                                                                                                                  \
+    }                                                                                                                                   \
+    hipLaunchKernelGGL((gemm_ring_kernel<A_, B_>), grid, dim3(512), ring_gemm_bytes(), st, g);                                          \
+  }
+    if (amode == 0 && bmode == 0) LP_RING(0, 0) else if (amode == 0 && bmode == 1) LP_RING(0, 1)
+    else if (amode == 1 && bmode == 0) LP_RING(1, 0) else LP_RING(1, 1)
+#undef LP_RING
     LP_LAUNCH_CHECK();
     return LIPASR_OK;
   }
   if (use_lds_gemm(g.M, g.N, g.K, g.lds_min_tiles)) {
     const dim3 grid((g.N + 63) / 64, (g.M + 63) / 64);
     constexpr size_t lds_b = lds_gemm_bytes(kLdsBKMax);
-#define LP_LDS(A_, B_)                                                                              \
-  {                                                                                                 \
-    static bool attr_set_dev[16] = {}; int attr_dev = 0; (void)hipGetDevice(&attr_dev); bool& attr_set = attr_set_dev[attr_dev & 15];  /* per device */                                                                   \
-    if (!attr_set) {                                                                                \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_lds_kernel<A_, B_, true>),       \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);            \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_lds_kernel<A_, B_, false>),      \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);            \
-      attr_set = true;                                                                              \
-    }                                                                                               \
-    if (g.bf16) hipLaunchKernelGGL((gemm_lds_kernel<A_, B_, true>), grid, dim3(512), lds_b, st, g); \
-    else hipLaunchKernelGGL((gemm_lds_kernel<A_, B_, false>), grid, dim3(512), lds_b, st, g);       \
+#define LP_LDS(A_, B_)                                                                                                                  \
+  {                                                                                                                                     \
+    static bool attr_set_dev[16] = {}; int attr_dev = 0; (void)hipGetDevice(&attr_dev); bool& attr_set = attr_set_dev[attr_dev & 15];   \
+    if (!attr_set) {                                                                                                                    \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_lds_kernel<A_, B_, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b); \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_lds_kernel<A_, B_, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b); \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_lds_kernel<A_, B_, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b); \
+      attr_set = true;                                                                                                                  \
+    }                                                                                                                                   \
+    if (g.bf16 == 2) hipLaunchKernelGGL((gemm_lds_kernel<A_, B_, 2>), grid, dim3(512), lds_b, st, g);                                   \
+    else if (g.bf16 == 1) hipLaunchKernelGGL((gemm_lds_kernel<A_, B_, 1>), grid, dim3(512), lds_b, st, g);                              \
+    else hipLaunchKernelGGL((gemm_lds_kernel<A_, B_, 0>), grid, dim3(512), lds_b, st, g);                                               \
   }
     if (amode == 0 && bmode == 0) LP_LDS(0, 0) else if (amode == 0 && bmode == 1) LP_LDS(0, 1)
     else if (amode == 1 && bmode == 0) LP_LDS(1, 0) else LP_LDS(1, 1)
@@ -1200,22 +1504,28 @@ static bool bnx_fits(const lipasr_mlp* m, bool forward, int M, int N, int K) {
   if (row_tiles > m->xc_rt_max || row_tiles > 64) return false;
   // [forward | backward][fragment | LDS kernel][fp32 | bf16 operands], filled on first use (one device per process in practice;
   // the kernels' resource use does not depend on the device)
-  static int per_cu[2][2][2] = {{{-1, -1}, {-1, -1}}, {{-1, -1}, {-1, -1}}};
-  int& pc = per_cu[forward ? 0 : 1][lds_k ? 1 : 0][m->compute_bf16 ? 1 : 0];
+  static int per_cu[2][2][3] = {{{-1, -1, -1}, {-1, -1, -1}}, {{-1, -1, -1}, {-1, -1, -1}}};
+  const int ar = m->compute_bf16;
+  int& pc = per_cu[forward ? 0 : 1][lds_k ? 1 : 0][ar];
   if (pc < 0) {
     const size_t lds_f = (size_t)(4 * 32 * 32 + 4 * 8 * 8) * sizeof(float);
-    if (forward) {
-      if (lds_k) pc = m->compute_bf16 ? blocks_per_cu(gemm_lds_kernel<0, 1, true, kLdsBKMax, true>, 512, lds_gemm_bytes(kLdsBKMax))
-                                      : blocks_per_cu(gemm_lds_kernel<0, 1, false, kLdsBKMax, true>, 512, lds_gemm_bytes(kLdsBKMax));
-      else pc = m->compute_bf16 ? blocks_per_cu(gemm_f32_kernel<0, 1, 4, true, true>, 256, lds_f) : blocks_per_cu(gemm_f32_kernel<0, 1, 4, false, true>, 256, lds_f);
-    } else {
-      if (lds_k) pc = m->compute_bf16 ? blocks_per_cu(gemm_lds_kernel<0, 0, true, kLdsBKMax, true>, 512, lds_gemm_bytes(kLdsBKMax))
-                                      : blocks_per_cu(gemm_lds_kernel<0, 0, false, kLdsBKMax, true>, 512, lds_gemm_bytes(kLdsBKMax));
-      else pc = m->compute_bf16 ? blocks_per_cu(gemm_f32_kernel<0, 0, 4, true, true>, 256, lds_f) : blocks_per_cu(gemm_f32_kernel<0, 0, 4, false, true>, 256, lds_f);
-    }
+#define LP_M(AR)                                                                                                              \
+  if (forward) pc = lds_k ? blocks_per_cu(gemm_lds_kernel<0, 1, AR, kLdsBKMax, true>, 512, lds_gemm_bytes(kLdsBKMax))       \
+                          : blocks_per_cu(gemm_f32_kernel<0, 1, 4, AR, true>, 256, lds_f);                                   \
+  else pc = lds_k ? blocks_per_cu(gemm_lds_kernel<0, 0, AR, kLdsBKMax, true>, 512, lds_gemm_bytes(kLdsBKMax))               \
+                  : blocks_per_cu(gemm_f32_kernel<0, 0, 4, AR, true>, 256, lds_f);
+    LP_DISPATCH_AR(ar, LP_M);
+#undef LP_M
+  }
+  int per = pc;
+  if (ar == 2 && lds_k) {  // the launch may take the LDS-DMA ring instance (68 KB of LDS): the smaller of the two answers
+    static int ring_pc[2] = {-1, -1};
+    int& rp = ring_pc[forward ? 0 : 1];
+    if (rp < 0) rp = forward ? blocks_per_cu(gemm_ring_kernel<0, 1, true>, 512, ring_gemm_bytes()) : blocks_per_cu(gemm_ring_kernel<0, 0, true>, 512, ring_gemm_bytes());
+    per = std::min(per, rp);
   }
   const int cus = m->cu_budget > 0 ? std::min(m->cu_budget, m->n_cus) : m->n_cus;
-  return pc > 0 && tiles <= (long)pc * cus;
+  return per > 0 && tiles <= (long)per * cus;
 }
 
 static GemmArgs gemm_args(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
@@ -1224,7 +1534,32 @@ static GemmArgs gemm_args(const float* A, int lda, const float* B, int ldb, floa
   memset(&g, 0, sizeof(g));
   g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.epi = epi;
   g.xcd_map = g_xcd_map;
+  g.sa = g.sb = 1.0f;
   return g;
+}
+
+// arithmetic mode of a plan's GEMM + the fp16 range scales of mode 2 by operand kind.  Powers of two (exact): activations and
+// features x 2^4 (|x| < 4094: raw MFCCs reach 700), kernels x 2^12 (|w| < 16), gradients x 2^8 / 2^floor(log2 g0) where g0 is the
+// size of the gradient at the network's output (the loss gradient is <= 1 / batch: a batch of 1024 gives 2^18, and room for the
+// gradient to grow 256-fold on its way down).  A value outside its range becomes inf in the fp16 conversion and the loss NaN --
+// loud, not silently wrong.  The low plane keeps its full 11 bits while |x| scale >= 2^-3 and degrades gradually below (fp16
+// subnormals): with the first gradient scale tried, a fixed 2^14, the bias gradients of a 1024-row batch (sums of 1024 terms of
+// 1e-6 that cancel to 5e-7) came out 9e-5 off; scaled by the batch they are inside the exact mode's 5e-5.
+enum OperandKind { OP_ACT = 0, OP_WEIGHT = 1, OP_GRAD = 2 };
+static float grad_scale_for(float g0) {  // g0: bound of the gradient at the logits (inv_batch, or 1 for a caller-given upstream vector)
+  int e = 0;
+  (void)frexpf(g0 > 0.0f ? g0 : 1.0f, &e);  // g0 = f 2^e, f in [0.5, 1)
+  return ldexpf(1.0f, 8 - e);               // 2^8 / 2^e >= 2^8 / (2 g0)
+}
+static void set_arith(GemmArgs& g, const lipasr_mlp* m, int kind_a, int kind_b, float g0 = 1.0f, bool training = true) {
+  // Mode 2 is a TRAINING arithmetic: there the activations are BatchNorm outputs (bounded by construction) and the gradients carry
+  // their own measured scale.  Inference-mode activations have no such bound (BatchNorm with moving statistics that have not
+  // adapted yet passes 1e4-sized values: the fp16 conversion overflowed in the first suite run) -- predict / attacks / class
+  // gradients stay on the exact fp32 chains, so every logit-parity statement is about exact fp32 whatever the training mode.
+  g.bf16 = (m->compute_bf16 == 2 && !training) ? 0 : m->compute_bf16;
+  const float sc[3] = {16.0f, 4096.0f, grad_scale_for(g0)};
+  g.sa = sc[kind_a];
+  g.sb = sc[kind_b];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1399,6 +1734,7 @@ struct BnBwdArgs {
   const float* save_mean;
   float* dgamma;
   float* dbeta;
+  unsigned* amax_out;  // arithmetic mode 2: max |dz| is folded into this word (see GemmArgs::amax_out); may be null
 };
 
 // backward of BatchNorm(train) -> ReLU given the column sums; also writes dgamma / dbeta
@@ -1425,7 +1761,8 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(BnBwdArgs p) {
   ColLane cc = c;
   if (!live) { cc.j = 0; cc.vec = false; cc.N = 0; }
   sum_partials(p.part, p.n_tiles, cc, rl, lds, cl, s1, s2);
-  if (!live) return;
+  float omax = 0.0f;
+  if (live) {
   float mean[4], rstd[4], ga[4], dbt[4], dg[4];
   ld4(p.save_mean, 0, c, mean);
   ld4(p.save_mean, (size_t)p.N, c, rstd);
@@ -1453,9 +1790,12 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(BnBwdArgs p) {
       const float xh = (av[e] - mean[e]) * rstd[e];
       const float d = ga[e] * rstd[e] * (gv[e] - dbt[e] * invB - xh * dg[e] * invB);
       o[e] = av[e] > 0.0f ? d : 0.0f;
+      if (c.j + e < c.N) omax = fmaxf(omax, fabsf(o[e]));
     }
     st4(p.dz, ro, c, o);
   }
+  }
+  if (p.amax_out) amax_publish(p.amax_out, omax);
 }
 
 // upstream vector at the network output -> dz at the logits, one thread per row (class_gradient and the
@@ -1554,6 +1894,21 @@ int lipasr_gemm_f32(lipasr_handle_t h, int transA, int transB, int M, int N, int
   return launch_gemm(transA ? 1 : 0, transB ? 0 : 1, g, S(stream));
 }
 
+int lipasr_gemm_f16x2(lipasr_handle_t h, int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B,
+                      int ldb, float* C, int ldc, float scale_a, float scale_b, lipasr_stream_t stream) {
+  LP_CHECK_ARG(h && A && B && C, "lipasr_gemm_f16x2: null argument");
+  LP_CHECK_ARG(M > 0 && N > 0 && K > 0, "lipasr_gemm_f16x2: empty problem %dx%dx%d", M, N, K);
+  LP_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, "lipasr_gemm_f16x2: leading dimension too small");
+  int ea = 0, eb = 0;
+  LP_CHECK_ARG(scale_a > 0.0f && scale_b > 0.0f && frexpf(scale_a, &ea) == 0.5f && frexpf(scale_b, &eb) == 0.5f,
+               "lipasr_gemm_f16x2: the scales must be powers of two (got %g, %g)", (double)scale_a, (double)scale_b);
+  GemmArgs g = gemm_args(A, lda, B, ldb, C, ldc, M, N, K, EPI_STORE);
+  g.bf16 = 2;
+  g.sa = scale_a;
+  g.sb = scale_b;
+  return launch_gemm(transA ? 1 : 0, transB ? 0 : 1, g, S(stream));
+}
+
 int lipasr_mlp_create(lipasr_handle_t h, int n_layers, const int* widths, const int* bn, const float* dropout,
                       const int* nonneg, int max_batch, lipasr_mlp_t* out) {
   LP_CHECK_ARG(h && widths && out, "lipasr_mlp_create: null argument");
@@ -1622,7 +1977,7 @@ int lipasr_mlp_create(lipasr_handle_t h, int n_layers, const int* widths, const 
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, h->device) == hipSuccess) m->n_cus = prop.multiProcessorCount;
     m->xc_rt_max = std::min((max_batch + 31) / 32, 64);
-    size_t go = 0, co = 16;  // control word 0: the error word (its own 64-byte slot)
+    size_t go = 0, co = 32;  // control words 0 .. 15: the error word (its own 64-byte slot), 16 .. 31: amax[layer]
     for (int dir = 0; dir < 2; ++dir)
       for (int l = 0; l + 1 < n_layers; ++l) {
         if (!m->L[l].bn) continue;
@@ -1630,15 +1985,21 @@ int lipasr_mlp_create(lipasr_handle_t h, int n_layers, const int* widths, const 
         m->xc_gran_off[dir][l] = go; go += nblk * m->xc_rt_max * 128;
         m->xc_ctrl_off[dir][l] = co; co += nblk * 32;
       }
+    if (hipMalloc(&m->xc_ctrl, co * sizeof(unsigned)) != hipSuccess) {
+      (void)hipGetLastError();
+      mlp_plan_free(m);
+      set_error("lipasr_mlp_create: control-word allocation failed");
+      return LIPASR_ENOMEM;
+    }
+    (void)hipMemset(m->xc_ctrl, 0, co * sizeof(unsigned));
+    m->xc_err = reinterpret_cast<int*>(m->xc_ctrl);
+    m->amax = m->xc_ctrl + 16;
     if (go > 0) {
-      if (hipMalloc(&m->xc_gran, go * sizeof(unsigned long long)) != hipSuccess || hipMalloc(&m->xc_ctrl, co * sizeof(unsigned)) != hipSuccess) {
+      if (hipMalloc(&m->xc_gran, go * sizeof(unsigned long long)) != hipSuccess) {
         (void)hipGetLastError();
-        if (m->xc_gran) (void)hipFree(m->xc_gran);
-        m->xc_gran = nullptr; m->xc_ctrl = nullptr;  // no exchange state: the launch chain is used
+        m->xc_gran = nullptr;  // no exchange state: the launch chain is used
       } else {
         (void)hipMemset(m->xc_gran, 0, go * sizeof(unsigned long long));
-        (void)hipMemset(m->xc_ctrl, 0, co * sizeof(unsigned));
-        m->xc_err = reinterpret_cast<int*>(m->xc_ctrl);
       }
     }
   }
@@ -1737,7 +2098,7 @@ static int forward_infer(lipasr_mlp* m, const float* params, const float* bnstat
       // when H aliases A (no BN, no dropout) the ReLU output lands in H == A directly
       g.aux = (keep_a && L.offH != L.offA) ? (m->ws + L.offA) : nullptr;
     }
-    g.bf16 = m->compute_bf16;
+    set_arith(g, m, OP_ACT, OP_WEIGHT, 1.0f, false);
     int rc = launch_gemm(0, 1, g, st);
     if (rc != LIPASR_OK) return rc;
     hin = outp;
@@ -1748,7 +2109,7 @@ static int forward_infer(lipasr_mlp* m, const float* params, const float* bnstat
 // inference-mode backward to the input from dz at the logits (in m->ws + offDzLast).
 // final_mode 0: store dx; 1: fused sign step on x_adv.
 static int backward_infer(lipasr_mlp* m, const float* params, const float* bnstate, int batch, float* dx, float* x_adv,
-                          const float* x0, float alpha, float eps, hipStream_t st) {
+                          const float* x0, float alpha, float eps, hipStream_t st, float g0 = 1.0f) {
   const float* gin = m->ws + m->offDzLast;
   float* pp[2] = {m->ws + m->offG0, m->ws + m->offG1};
   int cur = 0;
@@ -1764,7 +2125,7 @@ static int backward_infer(lipasr_mlp* m, const float* params, const float* bnsta
         g.mvar = bnstate + P.offmv;
       }
       g.aux = m->ws + P.offA;
-      g.bf16 = m->compute_bf16;
+      set_arith(g, m, OP_GRAD, OP_WEIGHT, g0, false);
       int rc = launch_gemm(0, 0, g, st);
       if (rc != LIPASR_OK) return rc;
       gin = pp[cur];
@@ -1776,7 +2137,7 @@ static int backward_infer(lipasr_mlp* m, const float* params, const float* bnsta
       g.x0 = x0;
       g.alpha = alpha;
       g.eps = eps;
-      g.bf16 = m->compute_bf16;
+      set_arith(g, m, OP_GRAD, OP_WEIGHT, g0, false);
       int rc = launch_gemm(0, 0, g, st);
       if (rc != LIPASR_OK) return rc;
     }
@@ -1813,6 +2174,7 @@ static int train_fwd_bwd_impl(lipasr_mlp_t m, const float* params, float* bnstat
   LP_CHECK_ARG(!dropout || (dropout->mode >= 0 && dropout->mode <= 2), "lipasr_mlp_train_fwd_bwd: dropout mode %d",
                dropout ? dropout->mode : 0);
   hipStream_t st = S(stream);
+  m->last_inv_batch = inv_batch;
   const int Lc = m->n_layers;
   const int C = m->L[Lc - 1].n_out;
   float* ws = m->ws;
@@ -1836,6 +2198,7 @@ static int train_fwd_bwd_impl(lipasr_mlp_t m, const float* params, float* bnstat
                            last ? (fuse_ce ? EPI_BIAS_SOFTMAX_CE : EPI_BIAS) : (L.bn ? (bnx ? EPI_BIAS_RELU_BNX : EPI_BIAS_RELU_STATS) : EPI_BIAS_RELU));
     g.bias = params + L.offb;
     g.part = part;
+    if (m->compute_bf16 == 2 && !last) g.amax_zero = m->amax + l;  // the backward pass of this step folds max |dz_l| into it
     if (bnx) {
       g.xc_gran = m->xc_gran + m->xc_gran_off[0][l]; g.xc_ctrl = m->xc_ctrl + m->xc_ctrl_off[0][l]; g.xc_err = m->xc_err; g.xc_rt_max = m->xc_rt_max;
       // LIPASR_XC_NOWAIT=1 (timing probe only, results are WRONG): the exchange epilogue without its wait and sweep, to see what the
@@ -1855,7 +2218,7 @@ static int train_fwd_bwd_impl(lipasr_mlp_t m, const float* params, float* bnstat
       g.loss_rows = loss_rows;
       g.correct_rows = correct_rows;
     }
-    g.bf16 = m->compute_bf16;
+    set_arith(g, m, OP_ACT, OP_WEIGHT);
     g.lds_min_tiles = m->lds_min_tiles;
     if (LP_ON) {
       rc = launch_gemm(0, 1, g, st);
@@ -1918,7 +2281,12 @@ static int train_fwd_bwd_impl(lipasr_mlp_t m, const float* params, float* bnstat
       gx.gamma = params + P.offg;
       gx.dgamma = grads + P.offg; gx.dbeta = grads + P.offbe;
     }
-    gx.bf16 = m->compute_bf16;
+    set_arith(gx, m, OP_GRAD, OP_WEIGHT, inv_batch);
+    // arithmetic mode 2: the size of a gradient is not known beforehand (BatchNorm's rstd can amplify it 30-fold per layer in an
+    // untrained network): whoever writes dz_l folds max |dz_l| into amax[l], whoever multiplies with dz_l derives its scale from it
+    const bool dyn = m->compute_bf16 == 2;
+    if (dyn && l < Lc - 1 && L.bn) gx.sa_dyn = m->amax + l;
+    if (dyn && P.bn) gx.amax_out = m->amax + (l - 1);
     gx.lds_min_tiles = m->lds_min_tiles;
     if (LP_ON) {
       rc = launch_gemm(0, 0, gx, st);
@@ -1939,6 +2307,7 @@ static int train_fwd_bwd_impl(lipasr_mlp_t m, const float* params, float* bnstat
       b.n_tiles = sa.seg >= 0 ? 1 : stats_row_tiles(batch, P.n_out, L.n_out, m->lds_min_tiles);
       b.gamma = params + P.offg; b.save_mean = ws + P.offMean;
       b.dgamma = grads + P.offg; b.dbeta = grads + P.offbe;
+      b.amax_out = dyn ? m->amax + (l - 1) : nullptr;
       const dim3 grid((P.n_out + 127) / 128, (batch + kApplyRows - 1) / kApplyRows);
       hipLaunchKernelGGL(bn_apply_bwd_kernel, grid, apply_block, 0, st, b);
       LP_LAUNCH_CHECK();
@@ -1953,7 +2322,8 @@ static int train_fwd_bwd_impl(lipasr_mlp_t m, const float* params, float* bnstat
     gw[l] = gemm_args(lin, L.n_in, gin, L.n_out, grads + L.offW, L.n_out, L.n_in + 1, L.n_out, batch, EPI_STORE);
     gw[l].ones_row = 1;
     gw[l].extra_out = grads + L.offb;
-    gw[l].bf16 = m->compute_bf16;
+    set_arith(gw[l], m, OP_ACT, OP_GRAD, inv_batch);
+    if (m->compute_bf16 == 2 && l < Lc - 1 && L.bn) gw[l].sb_dyn = m->amax + l;
   }
   if (!LP_ON) return LIPASR_OK;
 #undef LP_ON
@@ -1986,7 +2356,8 @@ int lipasr_mlp_train_dw0(lipasr_mlp_t m, const float* x, int batch, float* grads
   GemmArgs g = gemm_args(x, L.n_in, m->ws + L.offDz, L.n_out, grads + L.offW, L.n_out, L.n_in + 1, L.n_out, batch, EPI_STORE);
   g.ones_row = 1;
   g.extra_out = grads + L.offb;
-  g.bf16 = m->compute_bf16;
+  set_arith(g, m, OP_ACT, OP_GRAD, m->last_inv_batch);
+  if (m->compute_bf16 == 2 && L.bn) g.sb_dyn = m->amax;
   return launch_gemm(1, 1, g, S(stream));
 }
 
@@ -2097,7 +2468,7 @@ static int attack_common(lipasr_mlp_t m, const float* params, const float* bnsta
                        (float*)nullptr);
     LP_LAUNCH_CHECK();
   }
-  return backward_infer(m, params, bnstate, batch, dx, x_adv, x0, alpha, eps, st);
+  return backward_infer(m, params, bnstate, batch, dx, x_adv, x0, alpha, eps, st, 1.0f / (float)batch);
 }
 
 int lipasr_mlp_input_grad(lipasr_mlp_t m, const float* params, const float* bnstate, const float* x,
@@ -2166,7 +2537,17 @@ int lipasr_mlp_exchange_errors(lipasr_mlp_t m, int* errors_host) {
 
 int lipasr_mlp_set_compute(lipasr_mlp_t m, int mode) {
   LP_CHECK_ARG(m != nullptr, "lipasr_mlp_set_compute: null plan");
-  LP_CHECK_ARG(mode == 0 || mode == 1, "lipasr_mlp_set_compute: mode %d (0 = fp32, 1 = bf16 operands)", mode);
+  LP_CHECK_ARG(mode >= 0 && mode <= 2, "lipasr_mlp_set_compute: mode %d (0 = exact fp32, 1 = bf16 operands, 2 = fp16 two-plane split)", mode);
+  if (mode == 2) {
+    // the split needs operands inside fp16's range: gradients carry a measured scale, kernels are small, and the activations are
+    // bounded because they are BatchNorm outputs -- so every hidden layer must have one (the reference's models do:
+    // train_constraints.py:67-85); a network without runs its activations up without bound (all-positive kernels: 1e4 and more)
+    for (int l = 0; l + 1 < m->n_layers; ++l)
+      if (!m->L[l].bn) {
+        set_error("lipasr_mlp_set_compute: mode 2 (fp16 two-plane split) needs BatchNormalization after every hidden Dense layer (layer %d has none); use mode 0", l);
+        return LIPASR_EUNSUPPORTED;
+      }
+  }
   m->compute_bf16 = mode;
   return LIPASR_OK;
 }

@@ -34,7 +34,8 @@ struct lipasr_mlp {
   float* ws = nullptr;  // workspace
   size_t ws_floats = 0;
   size_t offLogits = 0, offProb = 0, offDzLast = 0, offG0 = 0, offG1 = 0, offG2 = 0, offPart = 0;
-  int compute_bf16 = 0;  // lipasr_mlp_set_compute: 1 rounds the GEMM operands to bf16 at the MFMA (fp32 accumulate)
+  int compute_bf16 = 0;  // lipasr_mlp_set_compute: 0 exact fp32, 1 GEMM operands rounded to bf16 at the MFMA, 2 fp16 two-plane split (fp32 accumulate)
+  float last_inv_batch = 1.0f;  // the loss-gradient bound of the last training forward (mode 2's gradient scale in lipasr_mlp_train_dw0)
   int lds_min_tiles = 0;  // lipasr_mlp_set_gemm_tiles: training GEMMs take the LDS-tiled kernel from this many 64x64 tiles (0 = default)
   // Round 5: training-mode BatchNorm inside the GEMM that produces its input (dense.hip, "exchange epilogue").  The row tiles
   // of a 32- (or 64-) column block hand each other their column partial sums through memory INSIDE the launch, so the apply
@@ -46,6 +47,7 @@ struct lipasr_mlp {
   int xc_rt_max = 0;      // row tiles the granule regions hold (<= 64)
   unsigned long long* xc_gran = nullptr;
   unsigned* xc_ctrl = nullptr;
+  unsigned* amax = nullptr;  // device words [layer]: max |dz_layer| of the current step as float bits (arithmetic mode 2's gradient scales)
   int* xc_err = nullptr;  // device word: an exchange gave up (a workgroup of its column block never became resident)
   size_t xc_gran_off[2][LIPASR_MAX_LAYERS] = {};  // [forward | backward][layer], in granules
   size_t xc_ctrl_off[2][LIPASR_MAX_LAYERS] = {};  // in 32-bit words

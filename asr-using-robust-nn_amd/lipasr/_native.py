@@ -72,6 +72,7 @@ PROTOTYPES = {
     "lipasr_scaler_fit": (i32, [c_h, c_f, i32, i32, c_f, c_f, c_s]),
     "lipasr_scaler_apply": (i32, [c_h, c_f, i32, i32, c_f, c_f, c_f, c_s]),
     "lipasr_gemm_f32": (i32, [c_h, i32, i32, i32, i32, i32, c_f, i32, c_f, i32, c_f, i32, c_s]),
+    "lipasr_gemm_f16x2": (i32, [c_h, i32, i32, i32, i32, i32, c_f, i32, c_f, i32, c_f, i32, f32, f32, c_s]),
     "lipasr_mlp_create": (i32, [c_h, i32, PI, PI, C.POINTER(f32), PI, i32, C.POINTER(c_h)]),
     "lipasr_mlp_destroy": (i32, [c_h]),
     "lipasr_mlp_sizes": (i32, [c_h, C.POINTER(sz), C.POINTER(sz)]),

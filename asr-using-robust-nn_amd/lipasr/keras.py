@@ -318,11 +318,18 @@ class TensorBoard(Callback):
 
 # ------------------------------------------------------------------------------------------------
 class Model:
-    def __init__(self, inputs, outputs, device=None, seed=0, max_batch=1024, compute_dtype="float32"):
-        """compute_dtype: "float32" (exact fp32 MFMA: the parity arithmetic) or "bfloat16" (GEMM operands rounded to
-        bf16 at the matrix instruction, fp32 accumulation -- BASELINE config 2; everything else stays fp32)."""
-        if compute_dtype not in ("float32", "bfloat16"):
-            raise ValueError("compute_dtype must be 'float32' or 'bfloat16'")
+    def __init__(self, inputs, outputs, device=None, seed=0, max_batch=1024, compute_dtype=None):
+        """compute_dtype: "float32" (exact fp32 MFMA chains), "float16x2" (round 5: every GEMM operand split into two fp16 planes on the
+        fp16 matrix instruction, three of the four cross terms, fp32 accumulate: 22-bit operands, 2^-21 per product -- the
+        resampler's and the STFT's arithmetic; parameters, activations, BatchNorm, loss, Adam and the projections stay fp32) or
+        "bfloat16" (GEMM operands rounded to bf16: BASELINE config 2's arithmetic, NOT inside the 1e-3 logit bound)."""
+        self._compute_from_env = compute_dtype is None
+        if compute_dtype is None:  # (LIPASR_COMPUTE: sweep knob for the test suite and A/B runs)
+            import os as _os
+
+            compute_dtype = _os.environ.get("LIPASR_COMPUTE", "float32")
+        if compute_dtype not in ("float32", "bfloat16", "float16x2"):
+            raise ValueError("compute_dtype must be 'float32', 'float16x2' or 'bfloat16'")
         self._compute_dtype = compute_dtype
         chain = []
         node = outputs
@@ -388,6 +395,12 @@ class Model:
         N.register_owner(self)
         if self._compute_dtype == "bfloat16":
             N.check(N.lib.lipasr_mlp_set_compute(plan, 1))
+        elif self._compute_dtype == "float16x2":
+            rc = N.lib.lipasr_mlp_set_compute(plan, 2)
+            if rc == N.EUNSUPPORTED and self._compute_from_env:
+                self._compute_dtype = "float32"  # (the environment's default does not apply to a model without BatchNorm)
+            else:
+                N.check(rc)
         import os as _os
 
         if _os.environ.get("LIPASR_FUSE_BN", "1") == "0":  # A/B knob: BatchNorm as launches of its own (the round-4 chain)

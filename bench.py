@@ -176,7 +176,7 @@ def run_config(opt, pool, batch, rank, world, device, steps, warmup, profile):
         waves = (waves * 32768.0).round_().clamp_(-32768, 32767).to(torch.int16)
     n_batches = waves.shape[0] // batch
     # same seed on every rank: replicas start identical
-    model = get_model(max_batch=batch, seed=0, compute_dtype="bfloat16" if opt.get("bf16") else "float32")
+    model = get_model(max_batch=batch, seed=0, compute_dtype="bfloat16" if opt.get("bf16") else os.environ.get("LIPASR_COMPUTE", "float32"))
     model.compile(optimizer="adam", loss=CategoricalCrossentropy(), metrics=["accuracy"])
     # A2 "affine, precomputed": StandardScaler fitted once on the MFCCs of the WHOLE resident pool, as the reference fits it on its
     # whole dataset (train_constraints.py:28-35: fit_transform over train + dev + test) -- until round 4 a four-batch shortcut

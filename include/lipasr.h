@@ -172,6 +172,14 @@ int lipasr_scaler_apply(lipasr_handle_t h, const float* x, int n_rows, int n_fea
 int lipasr_gemm_f32(lipasr_handle_t h, int transA, int transB, int M, int N, int K, const float* A,
                     int lda, const float* B, int ldb, float* C, int ldc, lipasr_stream_t stream);
 
+/* (round 5) The same product in the classifier's third arithmetic mode (lipasr_mlp_set_compute(plan, 2)): every operand value,
+ * multiplied by scale_a / scale_b (powers of two that bring it inside fp16's range: |x scale| <= 65504, and best >= 2^-3),
+ * is split into two fp16 planes and three of the four cross terms run on v_mfma_f32_32x32x16_f16 with fp32 accumulation:
+ * 2^-21 per product where the exact mode's fma chain has 2^-24, at a quarter of the matrix time.  Large well-aligned problems
+ * (K a multiple of 32, leading dimensions multiples of 4, 16-byte aligned bases) take the LDS-DMA ring kernel. */
+int lipasr_gemm_f16x2(lipasr_handle_t h, int transA, int transB, int M, int N, int K, const float* A, int lda,
+                      const float* B, int ldb, float* C, int ldc, float scale_a, float scale_b, lipasr_stream_t stream);
+
 /* ------------------------------------------------------------------ K2/K5: the dense classifier plan
  * get_model() of train_constraints.py:63-88 / train_google_dataset.py:49-74 as data:
  * n_layers Dense layers, widths[0..n_layers]; hidden layers are Dense(relu) [-> BatchNorm]
@@ -280,7 +288,7 @@ int lipasr_mlp_product_norm(lipasr_mlp_t m, const float* params, float* sigma_ou
  * fp32 accumulation, on v_mfma_f32_32x32x16_bf16 -- BASELINE config 2's "bf16"; parameters,
  * activations, statistics, the loss, Adam and the projections stay fp32.  Takes effect from the
  * next launch; re-capture HIP graphs after changing it. */
-int lipasr_mlp_set_compute(lipasr_mlp_t m, int mode);
+int lipasr_mlp_set_compute(lipasr_mlp_t m, int mode);  /* 0 exact fp32, 1 bf16 operands, 2 (round 5) fp16 two-plane split: see lipasr_gemm_f16x2 */
 
 /* Kernel choice of the training pass's forward and dX GEMMs: from `lds_min_tiles` 64x64 output tiles on, the LDS-tiled
  * kernel instead of the 32x32 register-fragment one (0 = the built-in 224, about one tile per CU of a whole MI355X).  A

@@ -13,6 +13,7 @@ import torch
 
 from golden import inputs
 from helpers import build_model, dev, grads_of, load_params, read_params, rel_err
+from lipasr import keras as K
 from oracle import mlp_ref as P
 
 pytestmark = pytest.mark.gpu
@@ -455,3 +456,94 @@ def test_batchnorm_inside_the_gemm_over_thirty_steps(cuda):
     print(f"\nparameters after 30 steps: max |fused - chain| = {d:.3e} ({d / wmax:.2e} of the largest weight)")
     assert d <= 1e-6 * wmax + 1e-9, (d, wmax)
     assert float((res[0][1] - res[1][1]).abs().max()) <= 1e-5 * float(res[0][1].abs().max())
+
+
+# ------------------------------------------------------------------------------------------------
+# Round 5: fp16 two-plane split arithmetic (lipasr_mlp_set_compute(plan, 2), Model(compute_dtype="float16x2"))
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("batch", [1024, 182])
+def test_fp16_two_plane_mode_is_fp32_accurate(cuda, batch):
+    """Every GEMM operand split into two fp16 planes (hi = RNE(x), lo = RNE(x - hi)), three of the four cross terms on
+    v_mfma_f32_32x32x16_f16, fp32 accumulation: products of fp16 numbers are exact in fp32, the error is the 2^-22 of the
+    representation and the dropped lo lo term -- the resampler's and the STFT's arithmetic, now for the classifier's GEMMs.
+    Held to the SAME bounds against the float64 oracle as the exact-fp32 mode in test_full_model_forward_backward (gradients 5e-5
+    of the tensor's maximum, loss 1e-5), and the two modes are compared with each other: logits within 2e-6 relative of the
+    largest logit, gradients within 5e-5 -- two orders inside BASELINE's 1e-3, where the bf16 mode is 1e-2."""
+    spec = P.vd_constrained_spec()
+    p = _random_state(spec, 1)
+    rng = np.random.default_rng(batch)
+    x = rng.standard_normal((batch, 880)).astype(np.float32)
+    y = P.to_categorical(rng.integers(0, 10, batch), 10)
+    masks = [((rng.uniform(size=(batch, s.n_out)) > s.dropout) / (1 - s.dropout)).astype(np.float32) if s.dropout > 0 else None for s in spec]
+    ref = P.forward_backward(spec, p.astype(np.float64), x.astype(np.float64), y.astype(np.float64), masks=masks, training=True)
+    got, logits = {}, {}
+    for mode in ("float32", "float16x2"):
+        K.reset_layer_names()
+        m = _build_with_dtype(spec, mode, max_batch=batch)
+        load_params(m, p)
+        m.train_fwd_bwd(dev(x), dev(y), masks=[dev(k) if k is not None else None for k in masks])
+        got[mode] = grads_of(m, spec)
+        assert abs(float(m._loss_rows[:batch].mean()) - ref["loss"]) < 1e-5 * max(1.0, abs(ref["loss"]))
+        logits[mode] = m.predict_device(dev(x), logits=True).cpu().numpy()
+        assert m.exchange_errors() == 0
+        m.close()
+    for l in range(6):
+        for k in ("dW", "db"):
+            assert rel_err(got["float16x2"][k][l], ref[k][l]) < 5e-5, (k, l, rel_err(got["float16x2"][k][l], ref[k][l]))
+            assert rel_err(got["float16x2"][k][l], got["float32"][k][l]) < 5e-5, (k, l)
+        if spec[l].bn:
+            assert rel_err(got["float16x2"]["dgamma"][l], ref["dgamma"][l]) < 5e-5 and rel_err(got["float16x2"]["dbeta"][l], ref["dbeta"][l]) < 5e-5
+    d = np.abs(logits["float16x2"] - logits["float32"]).max() / np.abs(logits["float32"]).max()
+    print(f"\nfloat16x2 against float32, batch {batch}: logits {d:.2e} of the largest logit; dW0 {rel_err(got['float16x2']['dW'][0], got['float32']['dW'][0]):.2e}")
+    assert d < 2e-6 and (logits["float16x2"].argmax(1) == logits["float32"].argmax(1)).all()
+
+
+def _build_with_dtype(spec, compute_dtype, max_batch=1024):
+    from lipasr import keras as K2
+
+    inp = K2.Input((spec[0].n_in,))
+    node = inp
+    for i, s in enumerate(spec):
+        last = i == len(spec) - 1
+        node = K2.Dense(s.n_out, activation="softmax" if last else "relu", kernel_constraint=K2.NonNeg() if s.nonneg else None)(node)
+        if not last and s.bn:
+            node = K2.BatchNormalization()(node)
+        if not last and s.dropout > 0:
+            node = K2.Dropout(s.dropout)(node)
+    m = K2.Model(inputs=inp, outputs=node, max_batch=max_batch, compute_dtype=compute_dtype)
+    m.compile(optimizer="adam", loss=K2.CategoricalCrossentropy(), metrics=["accuracy"])
+    return m
+
+
+def _gemm_split(a, b, ta, tb, sa=16.0, sb=16.0):
+    from lipasr import _native as N
+
+    h = N.get_handle(0)
+    A = dev(a.T if ta else a)
+    B = dev(b.T if tb else b)
+    M, K_ = a.shape
+    Nn = b.shape[1]
+    out = torch.full((M, Nn), float("nan"), device="cuda")
+    N.check(N.lib.lipasr_gemm_f16x2(h.h, int(ta), int(tb), M, Nn, K_, N.ptr(A), A.shape[1], N.ptr(B), B.shape[1], N.ptr(out), Nn, sa, sb, N.stream_ptr()))
+    return out.cpu().numpy()
+
+
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("shape", [(1024, 1024, 896), (1024, 512, 1024), (512, 256, 64), (192, 128, 32), (1024, 64, 128),   # LDS-DMA ring kernel
+                                   (512, 1024, 880), (182, 10, 64), (33, 47, 21), (100, 72, 50), (512, 880, 10)])              # the other tiles
+def test_gemm_f16x2_all_layouts(cuda, ta, tb, shape):
+    """lipasr_gemm_f16x2: every layout on both kernels of arithmetic mode 2 -- the LDS-DMA ring (K-contiguous operands through the
+    XOR-swizzled [i][32 k] slot image, k-major operands through [32 k][64 i]) and the register-staged / fragment tiles for shapes
+    the ring does not take.  Small integers are exact (they are fp16 numbers: catches a wrong swizzle or lane map exactly);
+    random operands are held to 6e-7 of sum |a||b| per element -- the two-plane split's 2^-21 per product."""
+    M, N_, K_ = shape
+    rng = np.random.default_rng(M + 7 * N_ + 13 * K_)
+    ai = rng.integers(-3, 4, (M, K_)).astype(np.float32)
+    bi = rng.integers(-3, 4, (K_, N_)).astype(np.float32)
+    np.testing.assert_array_equal(_gemm_split(ai, bi, ta, tb), ai.astype(np.float64) @ bi.astype(np.float64))
+    a = rng.standard_normal((M, K_)).astype(np.float32)
+    b = rng.standard_normal((K_, N_)).astype(np.float32)
+    ref = a.astype(np.float64) @ b.astype(np.float64)
+    bound = 6e-7 * (np.abs(a).astype(np.float64) @ np.abs(b).astype(np.float64)) + 1e-30
+    got = _gemm_split(a, b, ta, tb)
+    assert np.all(np.abs(got - ref) <= bound), float((np.abs(got - ref) / bound).max())
