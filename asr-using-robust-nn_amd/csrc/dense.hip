@@ -152,9 +152,13 @@ __device__ __forceinline__ void split8(const float (&x)[8], const float scale, f
 }
 // mode 2, operands whose size is not known beforehand (gradients): the producer's epilogue leaves max |x| as float bits; the
 // scale 2^(14 - e) with max = f 2^e, f in [0.5, 1), puts the largest value in [2^13, 2^14) -- a factor 4 under fp16's 65504
+// The maximum lives in kAmaxSlots words, one per 64-byte line: 2048 wavefronts folding their maxima into ONE word cost the backward
+// kernels 10-22 us each (atomics execute at the memory side, one address serialises them); spread over 64 lines they run side by
+// side, and a consumer reads the 64 words with one coalesced... strided load per wavefront and a wave maximum.
+constexpr int kAmaxSlots = 64, kAmaxStride = 16;  // words
 __device__ __forceinline__ float scale_from_amax(const unsigned* p, const float fallback) {
   if (!p) return fallback;
-  const float a = __uint_as_float(*p);
+  const float a = wave_max(__uint_as_float(p[(threadIdx.x & 63) * kAmaxStride]));
   if (!(a > 0.0f) || !(a < INFINITY)) return 1.0f;  // all zero, or NaN / inf (which then propagate as they should)
   int e = 0;
   (void)frexpf(a, &e);
@@ -162,7 +166,14 @@ __device__ __forceinline__ float scale_from_amax(const unsigned* p, const float 
 }
 __device__ __forceinline__ void amax_publish(unsigned* out, float m) {
   m = wave_max(m);
-  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));  // (non-negative floats order like their bits; NaN is the largest)
+  if ((threadIdx.x & 63) == 0) {
+    const unsigned w = (blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    atomicMax(out + (w & (kAmaxSlots - 1)) * kAmaxStride, __float_as_uint(m));  // (non-negative floats order like their bits; NaN is the largest)
+  }
+}
+// workgroup (0, 0) of a forward launch clears the words the backward pass of the same step will fold into
+__device__ __forceinline__ void amax_clear(unsigned* out) {
+  if (threadIdx.x < kAmaxSlots) out[threadIdx.x * kAmaxStride] = 0u;
 }
 // one 16-deep chunk: acc += a b on three fp16 matrix instructions
 __device__ __forceinline__ f32x16 mfma_split(const float (&a)[8], const float (&b)[8], const float sa, const float sb, f32x16 acc) {
@@ -522,7 +533,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
   if constexpr (X) xtag = xc_tag<32>(XcView{g.xc_gran, g.xc_ctrl, g.xc_err, g.xc_rt_max}, bx);
   float rsa = 1.0f, rsb = 1.0f;
   if (BF == 2) { rsa = scale_from_amax(g.sa_dyn, g.sa); rsb = scale_from_amax(g.sb_dyn, g.sb); }
-  if (g.amax_zero && bx == 0 && by == 0 && tid == 0) *g.amax_zero = 0u;
+  if (g.amax_zero && bx == 0 && by == 0) amax_clear(g.amax_zero);
   f32x16 acc;
 #pragma unroll
   for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
@@ -1012,7 +1023,7 @@ __device__ __forceinline__ void gemm_lds_tile(const GemmArgs& g, const int bx, c
   if constexpr (X) xtag = xc_tag<64>(XcView{g.xc_gran, g.xc_ctrl, g.xc_err, g.xc_rt_max}, bx);
   float rsa = 1.0f, rsb = 1.0f;
   if (BF == 2) { rsa = scale_from_amax(g.sa_dyn, g.sa); rsb = scale_from_amax(g.sb_dyn, g.sb); }
-  if (g.amax_zero && bx == 0 && by == 0 && tid == 0) *g.amax_zero = 0u;
+  if (g.amax_zero && bx == 0 && by == 0) amax_clear(g.amax_zero);
   f32x16 acc;
 #pragma unroll
   for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
@@ -1161,7 +1172,7 @@ __device__ __forceinline__ void gemm_ring_tile(const GemmArgs& g, const int bx, 
   unsigned xtag = 0;
   if constexpr (X) xtag = xc_tag<64>(XcView{g.xc_gran, g.xc_ctrl, g.xc_err, g.xc_rt_max}, bx);
   const float rsa = scale_from_amax(g.sa_dyn, g.sa), rsb = scale_from_amax(g.sb_dyn, g.sb);
-  if (g.amax_zero && bx == 0 && by == 0 && tid == 0) *g.amax_zero = 0u;
+  if (g.amax_zero && bx == 0 && by == 0) amax_clear(g.amax_zero);
   const float* pa = ring_src<AMODE>(g.A, g.lda, m0, m_real, wave, lane);
   const float* pb = ring_src<BMODE>(g.B, g.ldb, n0, g.N, wave, lane);
   const size_t sa_step = ring_step<AMODE>(g.lda), sb_step = ring_step<BMODE>(g.ldb);
@@ -1248,8 +1259,9 @@ __global__ __launch_bounds__(512) void gemm_ring_grouped_kernel(GemmGroup grp) {
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 // amode / bmode: 1 = the operand is k-major in memory (P[k ld + i])
+static int g_no_ring = 0;  // lipasr_debug_gemm_mode bit 5: arithmetic mode 2 on the register-staged tiles only (A/B knob)
 static bool ring_legal(int amode, int bmode, const GemmArgs& g) {
-  if (g.bf16 != 2 || g.M < 64 || g.N < 64 || g.K < 32 || (g.K & 31)) return false;
+  if (g_no_ring || g.bf16 != 2 || g.M < 64 || g.N < 64 || g.K < 32 || (g.K & 31)) return false;
   if ((g.lda & 3) || (g.ldb & 3) || !aligned16(g.A) || !aligned16(g.B)) return false;
   const int m_real = g.ones_row ? g.M - 1 : g.M;
   if (amode == 1 && ((m_real & 3) || m_real < 4)) return false;
@@ -1878,10 +1890,11 @@ using namespace lipasr;
 extern "C" {
 
 int lipasr_debug_gemm_mode(int mode) {
-  g_gemm_mode = mode & 3;
+  g_gemm_mode = mode & 3;  // (bits: 0-1 kernel choice, 2 split dW_0, 3 grouped launch on fragment tiles, 4 no XCD map, 5 no LDS-DMA ring)
   g_split_dw0 = (mode >> 2) & 1;
   g_group_lds = ((mode >> 3) & 1) ? 0 : 1;
   g_xcd_map = ((mode >> 4) & 1) ? 0 : 1;
+  g_no_ring = (mode >> 5) & 1;
   return LIPASR_OK;
 }
 
@@ -1977,7 +1990,8 @@ int lipasr_mlp_create(lipasr_handle_t h, int n_layers, const int* widths, const 
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, h->device) == hipSuccess) m->n_cus = prop.multiProcessorCount;
     m->xc_rt_max = std::min((max_batch + 31) / 32, 64);
-    size_t go = 0, co = 32;  // control words 0 .. 15: the error word (its own 64-byte slot), 16 .. 31: amax[layer]
+    const size_t amax_words = (size_t)LIPASR_MAX_LAYERS * kAmaxSlots * kAmaxStride;
+    size_t go = 0, co = 16 + amax_words;  // control words 0 .. 15: the error word (its own 64-byte slot), then amax[layer][slot]
     for (int dir = 0; dir < 2; ++dir)
       for (int l = 0; l + 1 < n_layers; ++l) {
         if (!m->L[l].bn) continue;
@@ -1993,7 +2007,7 @@ int lipasr_mlp_create(lipasr_handle_t h, int n_layers, const int* widths, const 
     }
     (void)hipMemset(m->xc_ctrl, 0, co * sizeof(unsigned));
     m->xc_err = reinterpret_cast<int*>(m->xc_ctrl);
-    m->amax = m->xc_ctrl + 16;
+    m->amax = m->xc_ctrl + 16;  // layer l: m->amax + l * kAmaxSlots * kAmaxStride
     if (go > 0) {
       if (hipMalloc(&m->xc_gran, go * sizeof(unsigned long long)) != hipSuccess) {
         (void)hipGetLastError();
@@ -2198,7 +2212,7 @@ static int train_fwd_bwd_impl(lipasr_mlp_t m, const float* params, float* bnstat
                            last ? (fuse_ce ? EPI_BIAS_SOFTMAX_CE : EPI_BIAS) : (L.bn ? (bnx ? EPI_BIAS_RELU_BNX : EPI_BIAS_RELU_STATS) : EPI_BIAS_RELU));
     g.bias = params + L.offb;
     g.part = part;
-    if (m->compute_bf16 == 2 && !last) g.amax_zero = m->amax + l;  // the backward pass of this step folds max |dz_l| into it
+    if (m->compute_bf16 == 2 && !last) g.amax_zero = m->amax + (size_t)l * kAmaxSlots * kAmaxStride;  // the backward pass of this step folds max |dz_l| into it
     if (bnx) {
       g.xc_gran = m->xc_gran + m->xc_gran_off[0][l]; g.xc_ctrl = m->xc_ctrl + m->xc_ctrl_off[0][l]; g.xc_err = m->xc_err; g.xc_rt_max = m->xc_rt_max;
       // LIPASR_XC_NOWAIT=1 (timing probe only, results are WRONG): the exchange epilogue without its wait and sweep, to see what the
@@ -2285,8 +2299,8 @@ static int train_fwd_bwd_impl(lipasr_mlp_t m, const float* params, float* bnstat
     // arithmetic mode 2: the size of a gradient is not known beforehand (BatchNorm's rstd can amplify it 30-fold per layer in an
     // untrained network): whoever writes dz_l folds max |dz_l| into amax[l], whoever multiplies with dz_l derives its scale from it
     const bool dyn = m->compute_bf16 == 2;
-    if (dyn && l < Lc - 1 && L.bn) gx.sa_dyn = m->amax + l;
-    if (dyn && P.bn) gx.amax_out = m->amax + (l - 1);
+    if (dyn && l < Lc - 1 && L.bn) gx.sa_dyn = m->amax + (size_t)l * kAmaxSlots * kAmaxStride;
+    if (dyn && P.bn) gx.amax_out = m->amax + (size_t)(l - 1) * kAmaxSlots * kAmaxStride;
     gx.lds_min_tiles = m->lds_min_tiles;
     if (LP_ON) {
       rc = launch_gemm(0, 0, gx, st);
@@ -2307,7 +2321,7 @@ static int train_fwd_bwd_impl(lipasr_mlp_t m, const float* params, float* bnstat
       b.n_tiles = sa.seg >= 0 ? 1 : stats_row_tiles(batch, P.n_out, L.n_out, m->lds_min_tiles);
       b.gamma = params + P.offg; b.save_mean = ws + P.offMean;
       b.dgamma = grads + P.offg; b.dbeta = grads + P.offbe;
-      b.amax_out = dyn ? m->amax + (l - 1) : nullptr;
+      b.amax_out = dyn ? m->amax + (size_t)(l - 1) * kAmaxSlots * kAmaxStride : nullptr;
       const dim3 grid((P.n_out + 127) / 128, (batch + kApplyRows - 1) / kApplyRows);
       hipLaunchKernelGGL(bn_apply_bwd_kernel, grid, apply_block, 0, st, b);
       LP_LAUNCH_CHECK();
@@ -2323,7 +2337,7 @@ static int train_fwd_bwd_impl(lipasr_mlp_t m, const float* params, float* bnstat
     gw[l].ones_row = 1;
     gw[l].extra_out = grads + L.offb;
     set_arith(gw[l], m, OP_ACT, OP_GRAD, inv_batch);
-    if (m->compute_bf16 == 2 && l < Lc - 1 && L.bn) gw[l].sb_dyn = m->amax + l;
+    if (m->compute_bf16 == 2 && l < Lc - 1 && L.bn) gw[l].sb_dyn = m->amax + (size_t)l * kAmaxSlots * kAmaxStride;
   }
   if (!LP_ON) return LIPASR_OK;
 #undef LP_ON

@@ -166,6 +166,11 @@ class TrainPipeline:
                     # after the grouped dW GEMM moved to LDS tiles: batch 1024: 0.614 / 0.431 / 0.453 with 64 / 96 / 128;
                     # batch 2048: 0.871 / 0.679 with 96 / 128; batch 512: 0.337 with 64
                     mfcc_cus = n_cu // 4 if self.batch <= 768 else ((n_cu * 3) // 8 if self.batch <= 1536 else n_cu // 2)
+                    # round 5: with the classifier's training GEMMs in arithmetic mode 2 (fp16 two-plane split, LDS-DMA ring) its
+                    # leg is 0.36 ms on 160 CUs and 0.37-0.38 on 128, so the extraction gets half the chip: batch 1024
+                    # 0.371 ms per step with 128 | 128 against 0.400 with 96 | 160 (200 steps, same box, interleaved)
+                    if getattr(self.model, "_compute_dtype", "float32") == "float16x2" and 768 < self.batch <= 1536:
+                        mfcc_cus = n_cu // 2
                 else:
                     mfcc_cus = n_cu // 2
         if not mfcc_cus or mfcc_cus >= n_cu:

@@ -145,6 +145,7 @@ def mfcc_source_sha():
     return h.hexdigest()[:16]
 
 
+DTYPE_NAMES = {"float32": "f32", "float16x2": "f32 accumulate, fp16 two-plane split products in the training GEMMs (22-bit operands)", "bfloat16": "bf16"}
 POOL_CLIPS = 65536                      # throughput runs loop a resident pool of >= 65 536 clips per GPU (4.2 GB)
 
 
@@ -176,7 +177,9 @@ def run_config(opt, pool, batch, rank, world, device, steps, warmup, profile):
         waves = (waves * 32768.0).round_().clamp_(-32768, 32767).to(torch.int16)
     n_batches = waves.shape[0] // batch
     # same seed on every rank: replicas start identical
-    model = get_model(max_batch=batch, seed=0, compute_dtype="bfloat16" if opt.get("bf16") else os.environ.get("LIPASR_COMPUTE", "float32"))
+    # arithmetic of the classifier's training GEMMs: "float16x2" (default since round 5: fp16 two-plane split products, fp32 accumulate,
+    # 2^-21 per product; inference / attack GEMMs and everything else exact fp32), "float32" (--exact-fp32: fp32 MFMA chains) or "bfloat16"
+    model = get_model(max_batch=batch, seed=0, compute_dtype="bfloat16" if opt.get("bf16") else opt.get("compute", "float16x2"))
     model.compile(optimizer="adam", loss=CategoricalCrossentropy(), metrics=["accuracy"])
     # A2 "affine, precomputed": StandardScaler fitted once on the MFCCs of the WHOLE resident pool, as the reference fits it on its
     # whole dataset (train_constraints.py:28-35: fit_transform over train + dev + test) -- until round 4 a four-batch shortcut
@@ -364,7 +367,8 @@ def _short(opt_over, pool, batch, device, steps, warmup):
     of one process; the cause was the training stream sharing a hardware queue (torch pool streams are multiplexed over 4) --
     TrainPipeline now gives it a queue of its own (scratch/pgd_fifth_probe.py: 4.07 ms as the fifth configuration,
     4.09 alone)."""
-    opt = {"constraint": "product", "pgd": 0, "pgd_eps": 0.5, "bf16": False, "pre_extracted": False, "graph": "auto", "int16": False}
+    opt = {"constraint": "product", "pgd": 0, "pgd_eps": 0.5, "bf16": False, "pre_extracted": False, "graph": "auto", "int16": False,
+           "compute": os.environ.get("LIPASR_COMPUTE", "float16x2")}
     opt.update(opt_over)
     try:
         sub = (pool[0][:16 * batch], pool[1][:16 * batch])  # (a pool shorter than 16 batches is used whole)
@@ -373,7 +377,7 @@ def _short(opt_over, pool, batch, device, steps, warmup):
         return {"error": f"{type(e).__name__}: {e}"[:200]}
     cls = TRAIN_FLOP_PER_UTT * batch / (ex["train_graph_ms"] * 1e-3) / 1e12 if not opt["pgd"] and ex["train_graph_ms"] > 0 else None
     return {"value": round(batch * steps / dt, 1), "unit": "utterances/sec", "ms_per_step": round(dt / steps * 1e3, 4), "per_gpu_batch": batch, "steps": steps,
-            "dtype": "bf16 operands, f32 accumulate" if opt["bf16"] else "f32", "train_graph_ms": round(ex["train_graph_ms"], 4),
+            "dtype": "bf16 operands, f32 accumulate" if opt["bf16"] else DTYPE_NAMES[opt["compute"]], "train_graph_ms": round(ex["train_graph_ms"], 4),
             "classifier_tflops": round(cls, 2) if cls else None, "mfcc_stream": ex.get("mfcc_stream"), "measured_in": "this process"}
 
 
@@ -423,6 +427,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="= --graph off")
     ap.add_argument("--bf16", action="store_true", help="classifier GEMM operands rounded to bf16 at the MFMA, fp32 accumulate (BASELINE config 2's "
                     "arithmetic); the default and the headline are exact fp32")
+    ap.add_argument("--exact-fp32", action="store_true", help="the classifier's training GEMMs on exact fp32 MFMA chains (v_mfma_f32_32x32x2_f32) instead of the "
+                    "default fp16 two-plane split (v_mfma_f32_32x32x16_f16 x 3, fp32 accumulate)")
     ap.add_argument("--pre-extracted", action="store_true", help="BASELINE config 2: train from resident (N,880) features, no MFCC stage")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--skip-b512", action="store_true")
@@ -432,7 +438,8 @@ def main():
     ap.add_argument("--dry-run-dp", action="store_true", help="rehearse the world > 1 control flow on the CPU (gloo, stand-in replica); prints a line marked dry_run, not a measurement")
     args = ap.parse_args()
     opt = {"constraint": None if args.constraint == "none" else args.constraint, "pgd": args.pgd, "pgd_eps": args.pgd_eps, "bf16": args.bf16,
-           "pre_extracted": args.pre_extracted, "graph": "off" if args.no_graph else args.graph, "int16": args.int16}
+           "pre_extracted": args.pre_extracted, "graph": "off" if args.no_graph else args.graph, "int16": args.int16,
+           "compute": "float32" if args.exact_fp32 else os.environ.get("LIPASR_COMPUTE", "float16x2")}
 
     from lipasr.parallel import init_from_env
 
@@ -545,12 +552,18 @@ def main():
     if args.pre_extracted:
         tf = TRAIN_FLOP_PER_UTT * batch / (ex["event_ms_per_step"] * 1e-3) / 1e12
         roofline = {"bound": "mfma", "achieved": round(tf, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP32_PEAK_TFLOPS, 5),
-                    "traffic": None, "stage": "dense classifier train step (v_mfma_f32_32x32x2_f32, exact fp32)",
+                    "traffic": None, "stage": "dense classifier train step (" + ("fp16 two-plane split on v_mfma_f32_32x32x16_f16 x 3: algorithmic fp32 FLOPs priced "
+                                                  "against the fp32 matrix peak" if opt["compute"] == "float16x2" and not args.bf16 else "v_mfma_f32_32x32x2_f32, exact fp32") + ")",
                     "algorithmic_flop_per_utt": TRAIN_FLOP_PER_UTT, "units_per_launch": batch,
                     "note": "whole step incl. BatchNorm, Adam and projection kernels; GEMM-only time is in profiles/"}
     out = {"metric": "utterances/sec (train, 1 s@16 kHz)", "value": round(value, 1), "unit": "utterances/sec", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
-           "scaling": args.scaling, "vs_baseline": None, "dtype": "bf16" if args.bf16 else "f32", "data": "synthetic",
+           "scaling": args.scaling, "vs_baseline": None, "dtype": "bf16" if args.bf16 else DTYPE_NAMES[opt["compute"]], "data": "synthetic",
+           # what "dtype" means here: parameters, activations, BatchNorm, loss, Adam, projection and every inference / attack GEMM are fp32;
+           # in mode float16x2 the training GEMMs split each fp32 operand into two fp16 planes and run three of the four cross terms on
+           # v_mfma_f32_32x32x16_f16 with fp32 accumulation -- 2^-21 per product (the K1 resampler's and STFT's technique).  The same
+           # step on exact fp32 MFMA chains is in "reference_exact_fp32_arithmetic"; tests/ hold both to the same oracle bounds
+           "arithmetic": {"training_gemms": opt["compute"], "everything_else": "float32"},
            "config": {"workload": ("pre-extracted standardised (N,880) MFCC features" if args.pre_extracted else "raw 16 kHz waveform -> on-GPU MFCC")
                                   + " -> Lipschitz-constrained MLP train step (Adam+NonNeg, simple_norm_constraint rho=0.1)" + (f" + PGD-{args.pgd} adversarial inner loop" if args.pgd else "")
                                   + (", data-parallel RCCL gradient all-reduce" if world > 1 else ", 1xMI355X"),
@@ -579,6 +592,8 @@ def main():
     if world == 1 and not args.skip_other_configs and not (args.pgd or args.pre_extracted or args.bf16):
         # the other single-GPU BASELINE configurations, in the driver-run record (short runs; each is its own model + pipeline)
         k, w = min(args.steps, 50), min(args.warmup, 10)
+        if opt["compute"] != "float32":  # the headline's step with the training GEMMs on exact fp32 MFMA chains (round 4's arithmetic)
+            out["reference_exact_fp32_arithmetic"] = _short({"compute": "float32"}, pool, batch, device, k, w)
         if batch != 8192:
             # north_star's 8-GPU bar is STRONG scaling at global batch 8192: this is its denominator -- the same step with all 8192
             # clips on one GPU (same pool, same pipeline, its own CU split).  8 x 1024-clip shards in T8 ms against this record's

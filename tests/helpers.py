@@ -6,8 +6,8 @@ from lipasr import keras as K
 from oracle import mlp_ref as P
 
 
-def build_model(spec, max_batch=1024, seed=0):
-    """lipasr.keras.Model with the structure of an oracle LayerSpec list."""
+def build_model(spec, max_batch=1024, seed=0, compute_dtype=None):
+    """lipasr.keras.Model with the structure of an oracle LayerSpec list (compute_dtype: None = the library's default, exact fp32)."""
     K.reset_layer_names()
     inp = K.Input((spec[0].n_in,))
     node = inp
@@ -18,7 +18,7 @@ def build_model(spec, max_batch=1024, seed=0):
             node = K.BatchNormalization()(node)
         if not last and s.dropout > 0:
             node = K.Dropout(s.dropout)(node)
-    m = K.Model(inputs=inp, outputs=node, max_batch=max_batch, seed=seed)
+    m = K.Model(inputs=inp, outputs=node, max_batch=max_batch, seed=seed, compute_dtype=compute_dtype)
     m.compile(optimizer="adam", loss=K.CategoricalCrossentropy(), metrics=["accuracy"])
     return m
 

@@ -317,7 +317,7 @@ def test_accuracy_parity_from_waveform(cuda, clips, seed):
     assert abs(acc_gpu - acc_ref) <= 0.005, (acc_gpu, acc_ref)
 
 
-def _train_constrained(spec, x, y, labels, seed, max_batch=512):
+def _train_constrained(spec, x, y, labels, seed, max_batch=512, compute=None):
     """train_constraints.py:91-111 with the protocol of tests/golden/make_constrained_acc.py: 400 epochs of 11 batches of
     128 in order, simple_norm_constraint(0.1) after every step, validation loss every 10 epochs, test accuracy at the
     best-validation-loss evaluation.  Returns (test accuracy at the best checkpoint, the model)."""
@@ -325,7 +325,7 @@ def _train_constrained(spec, x, y, labels, seed, max_batch=512):
     from lipasr.keras import Dataset
 
     tr, va, te = _split(seed)
-    m = build_model(spec, max_batch=max_batch, seed=seed)
+    m = build_model(spec, max_batch=max_batch, seed=seed, compute_dtype=compute)
     load_params(m, P.init_params(spec, seed=seed, dtype=np.float32, nonneg_init=True))
     ds = Dataset.from_tensor_slices((x[tr], y[tr])).batch(128)
     xv, yv, xt = dev(x[va]), dev(y[va]), dev(x[te])
@@ -339,8 +339,10 @@ def _train_constrained(spec, x, y, labels, seed, max_batch=512):
     return best[1], m
 
 
-def test_constrained_accuracy_product_vs_oracle(cuda, clips):
-    """BASELINE.json: "final top-1 accuracy within +-0.5 pt" for the model the north star names -- get_model() + NonNeg +
+@pytest.mark.parametrize("compute", ["float32", "float16x2"])
+def test_constrained_accuracy_product_vs_oracle(cuda, clips, compute):
+    """(compute: the training GEMMs on exact fp32 chains, or on round 5's fp16 two-plane split -- the bench's default -- held to the
+    same statement.)  BASELINE.json: "final top-1 accuracy within +-0.5 pt" for the model the north star names -- get_model() + NonNeg +
     simple_norm_constraint(0.1) after every batch (VD/train_constraints.py:63-111) -- PRODUCT against ORACLE.
 
     Oracle side: tests/golden/constrained_acc.npz, written on the CPU by tests/golden/make_constrained_acc.py: oracle.mlp_ref +
@@ -369,12 +371,12 @@ def test_constrained_accuracy_product_vs_oracle(cuda, clips):
     x = feats.cpu().numpy()
     acc = []
     for seed in seeds:
-        a, m = _train_constrained(spec, x, y, labels, seed)
+        a, m = _train_constrained(spec, x, y, labels, seed, compute=compute)
         m.close()
         acc.append(a)
     acc = np.array(acc)
     o_mean = 0.5 * (oa.mean() + ob.mean())
-    print(f"\nconstrained model, seeds {seeds}: test accuracy at the best-validation checkpoint\n  product (from the waveform) {acc} mean {acc.mean():.4f}"
+    print(f"\nconstrained model [{compute}], seeds {seeds}: test accuracy at the best-validation checkpoint\n  product (from the waveform) {acc} mean {acc.mean():.4f}"
           f"\n  oracle stream A {oa} mean {oa.mean():.4f}\n  oracle stream B {ob} mean {ob.mean():.4f}\n  oracle same-seed scatter max {scatter:.4f}")
     assert acc.min() > 0.95
     assert abs(acc.mean() - o_mean) <= 0.005  # +-0.5 pt, product mean against oracle mean
@@ -383,7 +385,8 @@ def test_constrained_accuracy_product_vs_oracle(cuda, clips):
     assert np.all((acc >= lo) & (acc <= hi)), (acc, lo, hi)
 
 
-def test_constrained_training_is_bitwise_reproducible(cuda, clips):
+@pytest.mark.parametrize("compute", ["float32", "float16x2"])
+def test_constrained_training_is_bitwise_reproducible(cuda, clips, compute):
     """DESIGN: no float atomics anywhere, Philox dropout keyed by (seed, element, layer, step) => the same seed on the same
     features gives the SAME bits.  Two fresh models, 330 constrained steps each with the reference's dropout: every parameter,
     BatchNorm statistic and Adam moment must be bit-identical, so run-to-run accuracy scatter of this model is chaos
@@ -399,7 +402,7 @@ def test_constrained_training_is_bitwise_reproducible(cuda, clips):
     spec = P.vd_constrained_spec()
     states = []
     for _ in range(2):
-        m = build_model(spec, max_batch=512, seed=3)
+        m = build_model(spec, max_batch=512, seed=3, compute_dtype=compute)
         load_params(m, P.init_params(spec, seed=3, dtype=np.float32, nonneg_init=True))
         ds = Dataset.from_tensor_slices((x[tr], y[tr])).batch(128)
         m.fit(ds, epochs=30, verbose=0, callbacks=[simple_norm_constraint(0.1, [])])

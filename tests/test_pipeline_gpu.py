@@ -75,8 +75,10 @@ def test_pipeline_graph_equals_eager(cuda):
     assert torch.equal(results[0][2], results[1][2])
 
 
-def test_pipeline_matches_oracle_training_steps(cuda):
-    """3 end-to-end steps (MFCC + fused standardisation -> train step -> simple_norm_constraint) against the oracle,
+@pytest.mark.parametrize("compute", ["float32", "float16x2"])
+def test_pipeline_matches_oracle_training_steps(cuda, compute):
+    """(compute: the arithmetic of the training GEMMs -- exact fp32 chains, or round 5's fp16 two-plane split, held to the same bounds.)
+    3 end-to-end steps (MFCC + fused standardisation -> train step -> simple_norm_constraint) against the oracle,
     dropout off.  The features are standardised (as train_constraints.py:28-35 does before fit): raw MFCCs are mostly
     negative, and behind non-negative kernels they leave every ReLU dead and every gradient exactly zero -- which is what
     this test compared in round 2."""
@@ -91,7 +93,7 @@ def test_pipeline_matches_oracle_training_steps(cuda):
     ref_feats = M.compute_mfcc_batch(waves)
     mean, scale = P.standard_scaler_fit(ref_feats)
     ref_std = (ref_feats - mean) / scale
-    m = build_model(spec, max_batch=32)
+    m = build_model(spec, max_batch=32, compute_dtype=compute)
     load_params(m, p)
     pipe = TrainPipeline(m, batch=32, rho=0.1, constraint="product", use_graph=True,
                          affine=(torch.as_tensor(mean).cuda(), torch.as_tensor(scale).cuda()))
