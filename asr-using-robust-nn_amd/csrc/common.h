@@ -45,6 +45,7 @@ struct lipasr_ctx {
   int rs_target_wgs = 256;  // persistent resampler: workgroups to aim for (lipasr_debug_set key 1); survives re-planning
   float* scratch = nullptr;
   size_t scratch_floats = 0;
+  float* zeros = nullptr;  // 256 bytes that stay zero (the LDS-DMA ring kernel's source for k >= K)
   std::vector<hipEvent_t> timers;  // pairs: 2*id = start, 2*id+1 = stop
   std::vector<hipGraphExec_t> graphs;
   std::vector<hipStream_t> streams;        // CU-masked streams made by lipasr_stream_create_masked and still alive

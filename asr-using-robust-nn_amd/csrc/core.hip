@@ -52,6 +52,11 @@ int lipasr_create(int device, lipasr_handle_t* out) {
     set_error("lipasr_create: scratch memset failed");
     return LIPASR_EHIP;
   }
+  if (hipMalloc(&c->zeros, 256) != hipSuccess || hipMemset(c->zeros, 0, 256) != hipSuccess) {
+    (void)hipGetLastError();
+    if (c->zeros) (void)hipFree(c->zeros);
+    c->zeros = nullptr;  // (the ring kernel then takes only K that are multiples of 32)
+  }
   *out = c;
   return LIPASR_OK;
 }
@@ -82,6 +87,7 @@ int lipasr_destroy(lipasr_handle_t h) {
   for (hipEvent_t e : h->timers) (void)hipEventDestroy(e);
   h->timers.clear();
   if (h->scratch) (void)hipFree(h->scratch);
+  if (h->zeros) (void)hipFree(h->zeros);
   delete h;
   return LIPASR_OK;
 }

@@ -94,6 +94,7 @@ struct GemmArgs {
   unsigned* amax_zero;     // forward launches: workgroup (0, 0) clears this word (the backward pass of the same step fills it)
   float sa, sb;       // arithmetic mode 2: powers of two that bring op(A) and B into fp16's range before the split (the accumulator is divided by sa sb)
   int lds_min_tiles;  // host side only: 64x64 tiles from which launch_gemm takes the LDS-tiled kernel (0 = the default)
+  const float* zeros; // >= 16 bytes of zeros in device memory (the ring kernel's source for k >= K in the last k-step), or null
   int ring;           // host side / grouped launch: this problem takes the LDS-DMA ring tile (mode 2, ring_legal)
   int xcd_map;        // 1: workgroup -> tile by xcd_tile() (a compact patch of the tile grid per XCD); 0: blockIdx as it comes
   // EPI_BIAS_RELU_BNX / EPI_DH_BNX (the exchange epilogue)
@@ -132,7 +133,11 @@ typedef float f32x2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split8(const float (&x)[8], const float scale, f16x8& hi, f16x8& lo) {
   float v[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) v[i] = x[i] * scale;
+  for (int i = 0; i < 8; ++i) v[i] = x[i];
+  if (scale != 1.0f) {  // (wave-uniform; activations run unscaled: the ring kernels are bound by vector-instruction issue, 8 multiplies of ~75 per k-step)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] *= scale;
+  }
   unsigned h[4], l[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) h[i] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2v){v[2 * i], v[2 * i + 1]}, f16x2v));
@@ -1116,7 +1121,10 @@ __device__ __forceinline__ void gemm_lds_tile(const GemmArgs& g, const int bx, c
 // Legal when K is a multiple of 32, both leading dimensions are multiples of 4, both bases 16-byte aligned and a k-major
 // operand's extent is a multiple of 4 (ring_legal); anything else takes gemm_lds_tile / gemm_tile, which handle every shape.
 // ---------------------------------------------------------------------------------------------
-constexpr int kRingStages = 4;
+#ifndef LIPASR_RING_STAGES
+#define LIPASR_RING_STAGES 4
+#endif
+constexpr int kRingStages = LIPASR_RING_STAGES;
 constexpr int kRingTile = 64 * 32;  // floats of one operand tile of one k-step (8 KB)
 constexpr size_t ring_gemm_bytes() { return (size_t)(kRingStages * 2 * kRingTile + 8 * 16 * 8) * sizeof(float); }
 
@@ -1168,9 +1176,13 @@ __device__ __forceinline__ void gemm_ring_tile(const GemmArgs& g, const int bx, 
   const int kh = wave >> 2, wi = (wave >> 1) & 1, wj = wave & 1;
   const int m0 = by * TS, n0 = bx * TS;
   const int m_real = g.ones_row ? g.M - 1 : g.M;
-  const int nst = g.K >> 5;
+  const int nst = (g.K + 31) >> 5;
   unsigned xtag = 0;
   if constexpr (X) xtag = xc_tag<64>(XcView{g.xc_gran, g.xc_ctrl, g.xc_err, g.xc_rt_max}, bx);
+  // K that is no multiple of 32 (the 880 features of layer 1): in the last k-step the lanes whose 16 bytes lie at k >= K fetch zeros
+  const int koff_a = AMODE == 1 ? 4 * wave + (lane >> 4) : 4 * ((lane & 7) ^ (((8 * wave + (lane >> 3)) >> 1) & 7));
+  const int koff_b = BMODE == 1 ? 4 * wave + (lane >> 4) : 4 * ((lane & 7) ^ (((8 * wave + (lane >> 3)) >> 1) & 7));
+  const bool k_tail = (g.K & 31) != 0;
   const float rsa = scale_from_amax(g.sa_dyn, g.sa), rsb = scale_from_amax(g.sb_dyn, g.sb);
   if (g.amax_zero && bx == 0 && by == 0) amax_clear(g.amax_zero);
   const float* pa = ring_src<AMODE>(g.A, g.lda, m0, m_real, wave, lane);
@@ -1179,8 +1191,9 @@ __device__ __forceinline__ void gemm_ring_tile(const GemmArgs& g, const int bx, 
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds) + (unsigned)wave * 1024u;  // this wavefront's 1 KB of an A tile
   auto issue = [&](const int t) {
     const unsigned slot = lds0 + (unsigned)(t % S) * (2u * kRingTile * 4u);
-    dma16(pa, slot);
-    dma16(pb, slot + kRingTile * 4u);
+    const bool last = k_tail && t == nst - 1;
+    dma16((last && 32 * t + koff_a >= g.K) ? g.zeros : pa, slot);
+    dma16((last && 32 * t + koff_b >= g.K) ? g.zeros : pb, slot + kRingTile * 4u);
     pa += sa_step;
     pb += sb_step;
   };
@@ -1199,11 +1212,15 @@ __device__ __forceinline__ void gemm_ring_tile(const GemmArgs& g, const int bx, 
     float* At = lds + (t % S) * 2 * kRingTile;
     if (il_ones >= 0 && lane < 4) At[(4 * wave + lane) * 64 + il_ones] = 1.0f;  // (this wavefront's own four k rows: they have landed)
     __syncthreads();  // every wavefront's part of k-step t is in LDS, and everybody is done with the slot of k-step t - 1
+#if !defined(LIPASR_RING_PROBE) || LIPASR_RING_PROBE != 2   // (timing probes, never shipped: 1 = no arithmetic, 2 = no operand traffic after the prologue)
     if (t + S - 1 < nst) issue(t + S - 1);
+#endif
+#if !defined(LIPASR_RING_PROBE) || LIPASR_RING_PROBE != 1
     float av[8], bv[8];
     ring_frag<AMODE>(At, 32 * wi + r, kh, hh, av);
     ring_frag<BMODE>(At + kRingTile, 32 * wj + r, kh, hh, bv);
     acc = mfma_split(av, bv, rsa, rsb, acc);
+#endif
   }
   {
     const float un = 1.0f / (rsa * rsb);
@@ -1261,7 +1278,8 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // amode / bmode: 1 = the operand is k-major in memory (P[k ld + i])
 static int g_no_ring = 0;  // lipasr_debug_gemm_mode bit 5: arithmetic mode 2 on the register-staged tiles only (A/B knob)
 static bool ring_legal(int amode, int bmode, const GemmArgs& g) {
-  if (g_no_ring || g.bf16 != 2 || g.M < 64 || g.N < 64 || g.K < 32 || (g.K & 31)) return false;
+  if (g_no_ring || g.bf16 != 2 || g.M < 64 || g.N < 64 || g.K < 32) return false;
+  if ((g.K & 31) && (!g.zeros || (g.K & 3))) return false;  // a K tail needs the zero source, and whole 16-byte chunks
   if ((g.lda & 3) || (g.ldb & 3) || !aligned16(g.A) || !aligned16(g.B)) return false;
   const int m_real = g.ones_row ? g.M - 1 : g.M;
   if (amode == 1 && ((m_real & 3) || m_real < 4)) return false;
@@ -1551,7 +1569,8 @@ static GemmArgs gemm_args(const float* A, int lda, const float* B, int ldb, floa
 }
 
 // arithmetic mode of a plan's GEMM + the fp16 range scales of mode 2 by operand kind.  Powers of two (exact): activations and
-// features x 2^4 (|x| < 4094: raw MFCCs reach 700), kernels x 2^12 (|w| < 16), gradients x 2^8 / 2^floor(log2 g0) where g0 is the
+// features unscaled (|x| < 65504; BatchNorm outputs are O(1): their low plane is a normal fp16 number down to |x| = 0.12 and loses
+// bits gradually below, on values that weigh little in a sum), kernels x 2^12 (|w| < 16), gradients x 2^8 / 2^floor(log2 g0) where g0 is the
 // size of the gradient at the network's output (the loss gradient is <= 1 / batch: a batch of 1024 gives 2^18, and room for the
 // gradient to grow 256-fold on its way down).  A value outside its range becomes inf in the fp16 conversion and the loss NaN --
 // loud, not silently wrong.  The low plane keeps its full 11 bits while |x| scale >= 2^-3 and degrades gradually below (fp16
@@ -1569,7 +1588,8 @@ static void set_arith(GemmArgs& g, const lipasr_mlp* m, int kind_a, int kind_b, 
   // adapted yet passes 1e4-sized values: the fp16 conversion overflowed in the first suite run) -- predict / attacks / class
   // gradients stay on the exact fp32 chains, so every logit-parity statement is about exact fp32 whatever the training mode.
   g.bf16 = (m->compute_bf16 == 2 && !training) ? 0 : m->compute_bf16;
-  const float sc[3] = {16.0f, 4096.0f, grad_scale_for(g0)};
+  g.zeros = reinterpret_cast<const float*>(m->xc_ctrl + 4);  // words 4 .. 7 of the control block: never written
+  const float sc[3] = {1.0f, 4096.0f, grad_scale_for(g0)};
   g.sa = sc[kind_a];
   g.sb = sc[kind_b];
 }
@@ -1919,6 +1939,7 @@ int lipasr_gemm_f16x2(lipasr_handle_t h, int transA, int transB, int M, int N, i
   g.bf16 = 2;
   g.sa = scale_a;
   g.sb = scale_b;
+  g.zeros = h->zeros;
   return launch_gemm(transA ? 1 : 0, transB ? 0 : 1, g, S(stream));
 }
 

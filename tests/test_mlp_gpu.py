@@ -530,7 +530,8 @@ def _gemm_split(a, b, ta, tb, sa=16.0, sb=16.0):
 
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
 @pytest.mark.parametrize("shape", [(1024, 1024, 896), (1024, 512, 1024), (512, 256, 64), (192, 128, 32), (1024, 64, 128),   # LDS-DMA ring kernel
-                                   (512, 1024, 880), (182, 10, 64), (33, 47, 21), (100, 72, 50), (512, 880, 10)])              # the other tiles
+                                   (1024, 1024, 880), (256, 128, 100), (128, 64, 36),                                        # ... with a K tail (zeros source)
+                                   (512, 1022, 880), (182, 10, 64), (33, 47, 21), (100, 72, 50), (512, 880, 10)])              # the other tiles
 def test_gemm_f16x2_all_layouts(cuda, ta, tb, shape):
     """lipasr_gemm_f16x2: every layout on both kernels of arithmetic mode 2 -- the LDS-DMA ring (K-contiguous operands through the
     XOR-swizzled [i][32 k] slot image, k-major operands through [32 k][64 i]) and the register-staged / fragment tiles for shapes
