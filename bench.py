@@ -509,7 +509,7 @@ def main():
     # the committed rocprofv3 measurement of the same kernels (separate --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH
     # doubled per MI355X_MICROARCH.md), scaled to this batch.
     traffic, traffic_src, traffic_fused, traffic_stale = None, None, None, None
-    for name in ("r04_mfcc_pmc.json", "r03_mfcc_pmc.json", "r02_mfcc_pmc.json"):
+    for name in ("r05_mfcc_pmc.json", "r04_mfcc_pmc.json", "r03_mfcc_pmc.json", "r02_mfcc_pmc.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 eor = json.load(f)["end_of_round"]
