@@ -303,7 +303,10 @@ int lipasr_mlp_set_gemm_tiles(lipasr_mlp_t m, int lds_min_tiles);
  * bn_apply_* launches of a step and their round trips go.  Bitwise reproducible (fixed summation order, no float atomics), equal
  * to the launch chain up to the order of the partial sums (1e-6).  mode 1 (default): wherever the launch's whole grid can be
  * resident on the CUs the plan may use and the batch has at most 64 row tiles; mode 0: the launch chain everywhere (the parity
- * reference).  Not used with synchronized BatchNorm (lipasr_mlp_train_segment). */
+ * reference).  Not used with synchronized BatchNorm (lipasr_mlp_train_segment).  The residency argument assumes that the plan's
+ * stream has its CUs to itself while a launch runs (one process per GPU, the library's contract): two processes that run large
+ * fused launches on ONE GPU at the same time can each hold slots the other waits for -- the exchanges then give up after 2 s and
+ * report through lipasr_mlp_exchange_errors; such a set-up wants mode 0. */
 int lipasr_mlp_set_fuse_bn(lipasr_mlp_t m, int mode);
 /* (round 5) How many CUs the stream this plan is launched on may use (a CU-masked stream: lipasr_stream_create_masked);
  * 0 = all of the device (default).  The exchange above spins until its column block's workgroups have all published, so the
