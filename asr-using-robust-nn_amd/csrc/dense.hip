@@ -95,6 +95,7 @@ struct GemmArgs {
   float sa, sb;       // arithmetic mode 2: powers of two that bring op(A) and B into fp16's range before the split (the accumulator is divided by sa sb)
   int lds_min_tiles;  // host side only: 64x64 tiles from which launch_gemm takes the LDS-tiled kernel (0 = the default)
   const float* zeros; // >= 16 bytes of zeros in device memory (the ring kernel's source for k >= K in the last k-step), or null
+  int cus;            // host side: CUs the launch may use (the plan's budget; 0 = unknown, the whole device)
   int ring;           // host side / grouped launch: this problem takes the LDS-DMA ring tile (mode 2, ring_legal)
   int xcd_map;        // 1: workgroup -> tile by xcd_tile() (a compact patch of the tile grid per XCD); 0: blockIdx as it comes
   // EPI_BIAS_RELU_BNX / EPI_DH_BNX (the exchange epilogue)
@@ -502,16 +503,21 @@ __device__ __forceinline__ void bnx_elem(const GemmArgs& g, const int step, cons
 // 8 x 4 tiles of the 16 x 16 grid of layer 1: a quarter of A and half of B, 2.7 MB, so both operands stay in that L2.
 // Bijective whenever it applies (ntx divisible by gx, nty by gy); otherwise the plain map.
 __device__ __forceinline__ void xcd_tile(const int L, const int ntx, const int nty, int& bx, int& by) {
-  int gx = 0, gy = 0;
-  if ((ntx & 1) == 0 && (nty & 3) == 0) { gx = 2; gy = 4; }
-  else if ((ntx & 3) == 0 && (nty & 1) == 0) { gx = 4; gy = 2; }
-  else if ((nty & 7) == 0) { gx = 1; gy = 8; }
-  else if ((ntx & 7) == 0) { gx = 8; gy = 1; }
-  if (gx == 0) { bx = L % ntx; by = L / ntx; return; }
-  const int xcd = L & 7, q = L >> 3, pw = ntx / gx, ph = nty / gy;
-  (void)ph;
-  bx = (xcd % gx) * pw + q % pw;
-  by = (xcd / gx) * ph + q / pw;
+  // Any grid (round 5; the first version needed ntx, nty divisible by the patch counts, and the 8 x 7 grid of 128-wide weight-gradient
+  // tiles fell to "one column of tiles per XCD": seven A panels + one B panel = 4 MB, the whole L2).  The tiles are put in a BLOCKED
+  // order -- row groups of height h, inside a group column by column -- and the 8 XCDs take consecutive runs of that order; XCD x runs
+  // the workgroups L = x (mod 8) in sequence, so its q-th workgroup takes the q-th tile of its run.  h ~ sqrt(run) makes a run
+  // roughly square: about 2 sqrt(run) operand panels instead of run + 1.
+  const int total = ntx * nty;
+  if (total < 16) { bx = L % ntx; by = L / ntx; return; }
+  const int xcd = L & 7, q = L >> 3, base = total >> 3, rem = total & 7;
+  const int t = xcd * base + min(xcd, rem) + q;            // position in the blocked order
+  int h = (int)(sqrtf((float)(base + (rem ? 1 : 0))) + 0.5f);
+  h = max(1, min(h, nty));
+  const int per_group = h * ntx, grp = t / per_group, u = t - grp * per_group;
+  const int hg = min(h, nty - grp * h);                     // height of this (maybe last, shorter) group
+  bx = u / hg;
+  by = grp * h + (u - bx * hg);
 }
 
 // One workgroup = one 32x32 output tile; its NW wavefronts (4, or 16 for small outputs with a long K) split K
@@ -1260,6 +1266,105 @@ __global__ __launch_bounds__(512) void gemm_lds_grouped_kernel(GemmGroup grp) {
   gemm_lds_tile<AMODE, BMODE, BF, kLdsBKMax>(g, bx, by, nty);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// The weight-gradient tile of arithmetic mode 2: 128 x 128 outputs per workgroup, TWO accumulators per wavefront.
+// The 64 x 64 ring tile above issues ~75 instructions per wavefront and k-step for 3 matrix instructions (one A and one B fragment
+// split per 32 x 32 x 16 product) and was bound by that (its probes: 56 us with the arithmetic compiled out, 64 us with the operand
+// traffic compiled out, 76 us whole, on 128 CUs).  Here wavefront (ri, cj) owns a 32 x 64 strip: per 16-deep chunk ONE A fragment is
+// split and multiplies TWO B fragments -- 36 split instructions and 24 LDS reads for 6 matrix instructions --, every wavefront takes the
+// whole 32-deep k-step (no K halves to add up afterwards), a k-step moves 32 KB for four times the 64 x 64 tile's arithmetic (half the
+// operand traffic per flop), and the accumulators go straight to memory (the epilogue of a weight gradient is a store).  Both operands
+// k-major (lin[k][i], dz[k][j]); ring of three k-steps = 96 KB, one workgroup per CU; 105 tiles for the reference's model.
+// ---------------------------------------------------------------------------------------------
+constexpr int kR128Stages = 3;
+constexpr int kR128Tile = 32 * 128;  // floats of one operand tile of one k-step (16 KB)
+constexpr size_t ring128_bytes() { return (size_t)(kR128Stages * 2 * kR128Tile) * sizeof(float); }
+
+__device__ __forceinline__ void gemm_ring128_tile(const GemmArgs& g, const int bx, const int by) {
+  constexpr int TS = 128, S = kR128Stages;
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [S][A | B][32 k][128]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, hh = lane >> 5;
+  const int ri = wave >> 1, cj = wave & 1;
+  const int m0 = by * TS, n0 = bx * TS;
+  const int m_real = g.ones_row ? g.M - 1 : g.M;
+  const int nst = (g.K + 31) >> 5;
+  const float rsa = scale_from_amax(g.sa_dyn, g.sa), rsb = scale_from_amax(g.sb_dyn, g.sb);
+  // DMA: an instruction moves 2 k rows of 128 floats; wavefront w moves k rows 4 w .. 4 w + 3 of both operands (two instructions each)
+  const int kl = 4 * wave + (lane >> 5), il = (lane & 31) * 4;
+  const float* pa = g.A + (size_t)kl * g.lda + min(m0 + il, m_real - 4);
+  const float* pb = g.B + (size_t)kl * g.ldb + min(n0 + il, g.N - 4);
+  const size_t a2 = (size_t)2 * g.lda, b2 = (size_t)2 * g.ldb, a32 = (size_t)32 * g.lda, b32 = (size_t)32 * g.ldb;
+  const bool k_tail = (g.K & 31) != 0;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds) + (unsigned)wave * 2048u;  // this wavefront's 4 k rows of an A tile
+  auto issue = [&](const int t) {
+    const unsigned slot = lds0 + (unsigned)(t % S) * (2u * kR128Tile * 4u);
+    const bool z0 = k_tail && 32 * t + kl >= g.K, z1 = k_tail && 32 * t + kl + 2 >= g.K;
+    dma16(z0 ? g.zeros : pa, slot);
+    dma16(z1 ? g.zeros : pa + a2, slot + 1024u);
+    dma16(z0 ? g.zeros : pb, slot + kR128Tile * 4u);
+    dma16(z1 ? g.zeros : pb + b2, slot + kR128Tile * 4u + 1024u);
+    pa += a32;
+    pb += b32;
+  };
+  const int pre = min(S - 1, nst);
+  for (int t = 0; t < pre; ++t) issue(t);
+  const int il_ones = (g.ones_row && g.M - 1 >= m0 && g.M - 1 < m0 + TS) ? g.M - 1 - m0 : -1;
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) { acc0[q] = 0.0f; acc1[q] = 0.0f; }
+  for (int t = 0; t < nst; ++t) {
+    const int ahead = min(t + S - 2, nst - 1) - t;  // k-steps requested beyond t: four DMA instructions each, completed in order
+    if (ahead >= 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float* At = lds + (t % S) * 2 * kR128Tile;
+    if (il_ones >= 0 && lane < 4) At[(4 * wave + lane) * TS + il_ones] = 1.0f;
+    __syncthreads();
+#if !defined(LIPASR_RING_PROBE) || LIPASR_RING_PROBE != 2
+    if (t + S - 1 < nst) issue(t + S - 1);
+#endif
+    const float* Bt = At + kR128Tile;
+#if !defined(LIPASR_RING_PROBE) || LIPASR_RING_PROBE != 1
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const float* qa = At + (16 * c + 8 * hh) * TS + 32 * ri + r;
+      const float* qb = Bt + (16 * c + 8 * hh) * TS + 64 * cj + r;
+      float av[8], b0[8], b1[8];
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8) {
+        av[s8] = qa[s8 * TS];
+        b0[s8] = qb[s8 * TS];
+        b1[s8] = qb[s8 * TS + 32];
+      }
+      f16x8 ah, al, bh, bl;
+      split8(av, rsa, ah, al);
+      split8(b0, rsb, bh, bl);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc0, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc0, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc0, 0, 0, 0);
+      split8(b1, rsb, bh, bl);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc1, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc1, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc1, 0, 0, 0);
+    }
+#else
+    (void)Bt;
+#endif
+  }
+  const float un = 1.0f / (rsa * rsb);
+  const int gn0 = n0 + 64 * cj + r, gn1 = gn0 + 32;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int gm = m0 + 32 * ri + (q & 3) + 8 * (q >> 2) + 4 * hh;
+    if (gm >= g.M) continue;
+    float* crow = (g.ones_row && gm == g.M - 1) ? g.extra_out : g.C + (size_t)gm * g.ldc;
+    if (gn0 < g.N) crow[gn0] = acc0[q] * un;
+    if (gn1 < g.N) crow[gn1] = acc1[q] * un;
+  }
+}
+
 // the grouped weight-gradient launch in arithmetic mode 2: every problem that is ring_legal on the LDS-DMA ring tile, the others
 // (the 64 x 10 output layer: its extent is no multiple of 4) on the register-staged tile
 __global__ __launch_bounds__(512) void gemm_ring_grouped_kernel(GemmGroup grp) {
@@ -1267,15 +1372,18 @@ __global__ __launch_bounds__(512) void gemm_ring_grouped_kernel(GemmGroup grp) {
   while (p + 1 < grp.n && (int)blockIdx.x >= grp.tile_start[p + 1]) ++p;
   const GemmArgs& g = grp.g[p];
   const int local = blockIdx.x - grp.tile_start[p];
-  const int ntx = (g.N + 63) / 64, nty = (g.M + 63) / 64;
+  const int ts = g.ring == 2 ? 128 : 64;
+  const int ntx = (g.N + ts - 1) / ts, nty = (g.M + ts - 1) / ts;
   int bx = local % ntx, by = local / ntx;
   if (g.xcd_map && (grp.tile_start[p] & 7) == 0) xcd_tile(local, ntx, nty, bx, by);
-  if (g.ring) gemm_ring_tile<1, 1>(g, bx, by, nty);
+  if (g.ring == 2) gemm_ring128_tile(g, bx, by);
+  else if (g.ring) gemm_ring_tile<1, 1>(g, bx, by, nty);
   else gemm_lds_tile<1, 1, 2, kLdsBKMax>(g, bx, by, nty);
 }
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 // amode / bmode: 1 = the operand is k-major in memory (P[k ld + i])
+static int g_ring_tile = 2;  // weight-gradient group: 2 = the 128 x 128 two-accumulator ring tile, 1 = the 64 x 64 ring tile (lipasr_debug_gemm_mode bit 6)
 static int g_no_ring = 0;  // lipasr_debug_gemm_mode bit 5: arithmetic mode 2 on the register-staged tiles only (A/B knob)
 static bool ring_legal(int amode, int bmode, const GemmArgs& g) {
   if (g_no_ring || g.bf16 != 2 || g.M < 64 || g.N < 64 || g.K < 32) return false;
@@ -1309,27 +1417,41 @@ static int launch_gemm_group_tn(const GemmArgs* gs, int n, hipStream_t st) {
       big += (long)((gs[done + k].N + 63) / 64) * ((gs[done + k].M + 63) / 64);
     const bool lds_tiles = g_group_lds && big >= 128 && gs[done].K >= 64;
     const int ts = lds_tiles ? 64 : 32;
+    const int ar = gs[done].bf16;
+    // 128 x 128 tiles (one workgroup per CU, half the operand traffic per flop, two accumulators per wavefront) where they fill the CUs
+    // the launch may use: the reference's model makes 109 of them -- 57 against 77 us on 128 CUs, 54 against 44 us on 256 (round 5)
+    int ring_tile = g_ring_tile;
+    if (ring_tile == 2 && lds_tiles && ar == 2) {
+      long n128 = 0;
+      for (int q = 0; q < kMaxGroup && done + q < n; ++q)
+        if (ring_legal(1, 1, gs[done + q])) n128 += (long)((gs[done + q].N + 127) / 128) * ((gs[done + q].M + 127) / 128);
+      int cus = gs[done].cus;
+      if (cus <= 0) { hipDeviceProp_t prop; int dev = 0; (void)hipGetDevice(&dev); cus = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256; }
+      if (10 * n128 < 6 * (long)cus) ring_tile = 1;
+    }
     int k = 0, tiles = 0;
+    bool any_ring = false;
     for (; k < kMaxGroup && done + k < n; ++k) {
       const GemmArgs& g = gs[done + k];
       if (g.M <= 0 || g.N <= 0 || g.K <= 0) { set_error("grouped gemm: empty problem"); return LIPASR_EINVAL; }
       grp.g[k] = g;
+      // arithmetic mode 2: the 128 x 128 two-accumulator ring tile for every problem it can take (g_ring_tile 1: the 64 x 64 ring tile)
+      if (lds_tiles && ar == 2 && ring_legal(1, 1, g)) { grp.g[k].ring = ring_tile; any_ring = true; }
+      const int tp = grp.g[k].ring == 2 ? 128 : ts;
       grp.tile_start[k] = tiles;
-      tiles += ((g.N + ts - 1) / ts) * ((g.M + ts - 1) / ts);
+      tiles += ((g.N + tp - 1) / tp) * ((g.M + tp - 1) / tp);
     }
     grp.n = k;
     grp.tile_start[k] = tiles;
-    const int ar = gs[done].bf16;
-    bool any_ring = false;
-    if (lds_tiles && ar == 2)
-      for (int q = 0; q < k; ++q) { grp.g[q].ring = ring_legal(1, 1, grp.g[q]) ? 1 : 0; any_ring = any_ring || grp.g[q].ring; }
     if (any_ring) {
+      const size_t lds_r = std::max(ring_gemm_bytes(), ring_tile == 2 ? ring128_bytes() : (size_t)0);
       static bool attr_set_dev[16] = {}; int attr_dev = 0; (void)hipGetDevice(&attr_dev); bool& attr_set = attr_set_dev[attr_dev & 15];
       if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring_grouped_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_gemm_bytes());
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring_grouped_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)std::max(ring_gemm_bytes(), ring128_bytes()));
         attr_set = true;
       }
-      hipLaunchKernelGGL(gemm_ring_grouped_kernel, dim3(tiles), dim3(512), ring_gemm_bytes(), st, grp);
+      hipLaunchKernelGGL(gemm_ring_grouped_kernel, dim3(tiles), dim3(512), lds_r, st, grp);
     } else if (lds_tiles) {
       constexpr size_t lds_b = lds_gemm_bytes(kLdsBKMax);
       static bool attr_set_dev[16] = {}; int attr_dev = 0; (void)hipGetDevice(&attr_dev); bool& attr_set = attr_set_dev[attr_dev & 15];  /* per device */
@@ -1354,7 +1476,9 @@ static int launch_gemm_group_tn(const GemmArgs* gs, int n, hipStream_t st) {
   return LIPASR_OK;
 }
 
-static int g_xcd_map = 1;    // lipasr_debug_gemm_mode bit 4 clears it: blockIdx -> tile as it comes (A/B knob)
+static int g_xcd_map = 0;    // lipasr_debug_gemm_mode bit 4 SETS it (round 5: measured, not kept): the XCD-aware blockIdx -> tile map of xcd_tile().
+                             // Same box, interleaved: config 2 0.3177 with it against 0.3148 without, config 3 0.3653 against 0.3625; the counters
+                             // (TCC hit 67 % on the weight-gradient launch either way) say the operand panels are not what misses.
 static int g_gemm_mode = 0;  // 0 auto, 1 split-K kernel only, 2 LDS kernel wherever it is legal (profiling knob)
 static int g_split_dw0 = 0;  // lipasr_debug_gemm_mode bit 2: the first layer's weight gradient as its own launch
 
@@ -1589,6 +1713,7 @@ static void set_arith(GemmArgs& g, const lipasr_mlp* m, int kind_a, int kind_b, 
   // gradients stay on the exact fp32 chains, so every logit-parity statement is about exact fp32 whatever the training mode.
   g.bf16 = (m->compute_bf16 == 2 && !training) ? 0 : m->compute_bf16;
   g.zeros = reinterpret_cast<const float*>(m->xc_ctrl + 4);  // words 4 .. 7 of the control block: never written
+  g.cus = m->cu_budget > 0 ? std::min(m->cu_budget, m->n_cus) : m->n_cus;
   const float sc[3] = {1.0f, 4096.0f, grad_scale_for(g0)};
   g.sa = sc[kind_a];
   g.sb = sc[kind_b];
@@ -1910,11 +2035,12 @@ using namespace lipasr;
 extern "C" {
 
 int lipasr_debug_gemm_mode(int mode) {
-  g_gemm_mode = mode & 3;  // (bits: 0-1 kernel choice, 2 split dW_0, 3 grouped launch on fragment tiles, 4 no XCD map, 5 no LDS-DMA ring)
+  g_gemm_mode = mode & 3;  // (bits: 0-1 kernel choice, 2 split dW_0, 3 grouped launch on fragment tiles, 4 XCD-aware tile map, 5 no LDS-DMA ring, 6 64 x 64 ring tile for the weight gradients)
   g_split_dw0 = (mode >> 2) & 1;
   g_group_lds = ((mode >> 3) & 1) ? 0 : 1;
-  g_xcd_map = ((mode >> 4) & 1) ? 0 : 1;
+  g_xcd_map = (mode >> 4) & 1;
   g_no_ring = (mode >> 5) & 1;
+  g_ring_tile = ((mode >> 6) & 1) ? 1 : 2;
   return LIPASR_OK;
 }
 

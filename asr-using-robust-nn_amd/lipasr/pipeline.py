@@ -225,7 +225,7 @@ class TrainPipeline:
                 self.train_cus = 8 * (n_groups - k)
                 # on part of the chip the LDS-tiled GEMM pays from fewer tiles on (layer 2 forward, the dX GEMM into layer 2:
                 # 128 tiles): -16 us on the classifier's graph at 160 CUs (PGD, which keeps every CU, loses 8 % with it)
-                N.check(N.lib.lipasr_mlp_set_gemm_tiles(self.model._plan, 128))
+                N.check(N.lib.lipasr_mlp_set_gemm_tiles(self.model._plan, int(os.environ.get("LIPASR_GEMM_TILES", "128"))))
                 # the fused BatchNorm exchange spins until a column block's workgroups are all resident: tell the plan how many
                 # CUs its stream really has (round 5)
                 N.check(N.lib.lipasr_mlp_set_cu_budget(self.model._plan, self.train_cus))
