@@ -14,6 +14,7 @@
 //   Epilogues fuse: bias (+ReLU), inference BatchNorm affine, the ReLU/BN backward mask of the
 //   inference-mode input gradient, and the FGSM/PGD sign step (K4) on the last backward GEMM.
 #include "mlp.h"
+#include <type_traits>
 
 namespace lipasr {
 
@@ -131,28 +132,49 @@ __device__ __forceinline__ bf16x8 to_bf16x8(const float (&v)[8]) {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
 typedef float f32x2v __attribute__((ext_vector_type(2)));
+// UNIT: the operand runs unscaled (activations): hi by v_cvt_pk_f16_f32, 12 vector instructions per 8 values.  Otherwise the power-of-two
+// scale rides in the conversions themselves, hi = f16(x s + 0) and lo = f16(x s - hi) on v_fma_mix (the scale from an SGPR): 16
+// instructions.  (The first version multiplied in front of a run-time `scale != 1` test, which the compiler turned into a multiply
+// AND two selects per pair of values: ~26 instructions per split, and the ring kernels are bound by vector-instruction issue.)
+template <bool UNIT>
 __device__ __forceinline__ void split8(const float (&x)[8], const float scale, f16x8& hi, f16x8& lo) {
-  float v[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) v[i] = x[i];
-  if (scale != 1.0f) {  // (wave-uniform; activations run unscaled: the ring kernels are bound by vector-instruction issue, 8 multiplies of ~75 per k-step)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] *= scale;
-  }
   unsigned h[4], l[4];
+  if constexpr (UNIT) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) h[i] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2v){v[2 * i], v[2 * i + 1]}, f16x2v));
-  asm("v_fma_mixlo_f16 %0, %4, 1.0, -%12 op_sel_hi:[0,0,1]\n\t"
-      "v_fma_mixlo_f16 %1, %6, 1.0, -%13 op_sel_hi:[0,0,1]\n\t"
-      "v_fma_mixlo_f16 %2, %8, 1.0, -%14 op_sel_hi:[0,0,1]\n\t"
-      "v_fma_mixlo_f16 %3, %10, 1.0, -%15 op_sel_hi:[0,0,1]\n\t"
-      "v_fma_mixhi_f16 %0, %5, 1.0, -%12 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
-      "v_fma_mixhi_f16 %1, %7, 1.0, -%13 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
-      "v_fma_mixhi_f16 %2, %9, 1.0, -%14 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
-      "v_fma_mixhi_f16 %3, %11, 1.0, -%15 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
-      "s_nop 1"
-      : "=&v"(l[0]), "=&v"(l[1]), "=&v"(l[2]), "=&v"(l[3])
-      : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(h[0]), "v"(h[1]), "v"(h[2]), "v"(h[3]));
+    for (int i = 0; i < 4; ++i) h[i] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2v){x[2 * i], x[2 * i + 1]}, f16x2v));
+    asm("v_fma_mixlo_f16 %0, %4, 1.0, -%12 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %1, %6, 1.0, -%13 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %2, %8, 1.0, -%14 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %3, %10, 1.0, -%15 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %0, %5, 1.0, -%12 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %1, %7, 1.0, -%13 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %2, %9, 1.0, -%14 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %3, %11, 1.0, -%15 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "s_nop 1"
+        : "=&v"(l[0]), "=&v"(l[1]), "=&v"(l[2]), "=&v"(l[3])
+        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "v"(h[0]), "v"(h[1]), "v"(h[2]), "v"(h[3]));
+  } else {
+    const float s = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, scale)));  // (wave-uniform by construction)
+    asm("v_fma_mixlo_f16 %0, %8, %16, 0 op_sel_hi:[0,0,0]\n\t"
+        "v_fma_mixlo_f16 %1, %10, %16, 0 op_sel_hi:[0,0,0]\n\t"
+        "v_fma_mixlo_f16 %2, %12, %16, 0 op_sel_hi:[0,0,0]\n\t"
+        "v_fma_mixlo_f16 %3, %14, %16, 0 op_sel_hi:[0,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %9, %16, 0 op_sel_hi:[0,0,0]\n\t"
+        "v_fma_mixhi_f16 %1, %11, %16, 0 op_sel_hi:[0,0,0]\n\t"
+        "v_fma_mixhi_f16 %2, %13, %16, 0 op_sel_hi:[0,0,0]\n\t"
+        "v_fma_mixhi_f16 %3, %15, %16, 0 op_sel_hi:[0,0,0]\n\t"
+        "v_fma_mixlo_f16 %4, %8, %16, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %5, %10, %16, -%1 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %6, %12, %16, -%2 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %7, %14, %16, -%3 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %4, %9, %16, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %5, %11, %16, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %6, %13, %16, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %7, %15, %16, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "s_nop 1"
+        : "=&v"(h[0]), "=&v"(h[1]), "=&v"(h[2]), "=&v"(h[3]), "=&v"(l[0]), "=&v"(l[1]), "=&v"(l[2]), "=&v"(l[3])
+        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "s"(s));
+  }
   hi = __builtin_bit_cast(f16x8, make_uint4(h[0], h[1], h[2], h[3]));
   lo = __builtin_bit_cast(f16x8, make_uint4(l[0], l[1], l[2], l[3]));
 }
@@ -182,10 +204,11 @@ __device__ __forceinline__ void amax_clear(unsigned* out) {
   if (threadIdx.x < kAmaxSlots) out[threadIdx.x * kAmaxStride] = 0u;
 }
 // one 16-deep chunk: acc += a b on three fp16 matrix instructions
+template <bool UA = false>  // UA: the A operand is unscaled (sa == 1: activations)
 __device__ __forceinline__ f32x16 mfma_split(const float (&a)[8], const float (&b)[8], const float sa, const float sb, f32x16 acc) {
   f16x8 ah, al, bh, bl;
-  split8(a, sa, ah, al);
-  split8(b, sb, bh, bl);
+  split8<UA>(a, sa, ah, al);
+  split8<false>(b, sb, bh, bl);
   acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
@@ -1210,24 +1233,29 @@ __device__ __forceinline__ void gemm_ring_tile(const GemmArgs& g, const int bx, 
   f32x16 acc;
 #pragma unroll
   for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
-  for (int t = 0; t < nst; ++t) {
-    const int ahead = min(t + S - 2, nst - 1) - t;  // k-steps requested beyond t: two DMA instructions each, completed in order
-    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    float* At = lds + (t % S) * 2 * kRingTile;
-    if (il_ones >= 0 && lane < 4) At[(4 * wave + lane) * 64 + il_ones] = 1.0f;  // (this wavefront's own four k rows: they have landed)
-    __syncthreads();  // every wavefront's part of k-step t is in LDS, and everybody is done with the slot of k-step t - 1
+  auto k_loop = [&](auto unit_a) {  // (two copies of the loop: an unscaled A operand -- the activations -- splits in 12 instructions instead of 16)
+    constexpr bool UA = decltype(unit_a)::value;
+    for (int t = 0; t < nst; ++t) {
+      const int ahead = min(t + S - 2, nst - 1) - t;  // k-steps requested beyond t: two DMA instructions each, completed in order
+      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      float* At = lds + (t % S) * 2 * kRingTile;
+      if (il_ones >= 0 && lane < 4) At[(4 * wave + lane) * 64 + il_ones] = 1.0f;  // (this wavefront's own four k rows: they have landed)
+      __syncthreads();  // every wavefront's part of k-step t is in LDS, and everybody is done with the slot of k-step t - 1
 #if !defined(LIPASR_RING_PROBE) || LIPASR_RING_PROBE != 2   // (timing probes, never shipped: 1 = no arithmetic, 2 = no operand traffic after the prologue)
-    if (t + S - 1 < nst) issue(t + S - 1);
+      if (t + S - 1 < nst) issue(t + S - 1);
 #endif
 #if !defined(LIPASR_RING_PROBE) || LIPASR_RING_PROBE != 1
-    float av[8], bv[8];
-    ring_frag<AMODE>(At, 32 * wi + r, kh, hh, av);
-    ring_frag<BMODE>(At + kRingTile, 32 * wj + r, kh, hh, bv);
-    acc = mfma_split(av, bv, rsa, rsb, acc);
+      float av[8], bv[8];
+      ring_frag<AMODE>(At, 32 * wi + r, kh, hh, av);
+      ring_frag<BMODE>(At + kRingTile, 32 * wj + r, kh, hh, bv);
+      acc = mfma_split<UA>(av, bv, rsa, rsb, acc);
 #endif
-  }
+    }
+  };
+  if (rsa == 1.0f) k_loop(std::true_type{});
+  else k_loop(std::false_type{});
   {
     const float un = 1.0f / (rsa * rsb);
 #pragma unroll
@@ -1315,6 +1343,8 @@ __device__ __forceinline__ void gemm_ring128_tile(const GemmArgs& g, const int b
   f32x16 acc0, acc1;
 #pragma unroll
   for (int q = 0; q < 16; ++q) { acc0[q] = 0.0f; acc1[q] = 0.0f; }
+  auto k_loop = [&](auto unit_a) {
+  constexpr bool UA = decltype(unit_a)::value;
   for (int t = 0; t < nst; ++t) {
     const int ahead = min(t + S - 2, nst - 1) - t;  // k-steps requested beyond t: four DMA instructions each, completed in order
     if (ahead >= 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -1339,12 +1369,12 @@ __device__ __forceinline__ void gemm_ring128_tile(const GemmArgs& g, const int b
         b1[s8] = qb[s8 * TS + 32];
       }
       f16x8 ah, al, bh, bl;
-      split8(av, rsa, ah, al);
-      split8(b0, rsb, bh, bl);
+      split8<UA>(av, rsa, ah, al);
+      split8<false>(b0, rsb, bh, bl);
       acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc0, 0, 0, 0);
       acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc0, 0, 0, 0);
       acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc0, 0, 0, 0);
-      split8(b1, rsb, bh, bl);
+      split8<false>(b1, rsb, bh, bl);
       acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc1, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc1, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc1, 0, 0, 0);
@@ -1353,6 +1383,9 @@ __device__ __forceinline__ void gemm_ring128_tile(const GemmArgs& g, const int b
     (void)Bt;
 #endif
   }
+  };
+  if (rsa == 1.0f) k_loop(std::true_type{});
+  else k_loop(std::false_type{});
   const float un = 1.0f / (rsa * rsb);
   const int gn0 = n0 + 64 * cj + r, gn1 = gn0 + 32;
 #pragma unroll
