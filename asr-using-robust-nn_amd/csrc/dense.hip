@@ -1398,6 +1398,136 @@ __device__ __forceinline__ void gemm_ring128_tile(const GemmArgs& g, const int b
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same 128 x 128 tile with a SPLIT PASS (round 5, after the counters): in the tile above every wavefront splits the fragments it
+// multiplies -- the A fragment of a strip is split by both wavefronts that share it, a B fragment by all four -- and the launch was
+// bound by that instruction stream (SQ counters on 128 CUs: 138 vector instructions per wavefront and k-step at ~6 cycles each, the
+// wavefronts 39 % issuing / 25 % stalled on issue / 36 % parked at the barrier, the matrix pipe 16 % busy).  Here a k-step's fp32
+// tile is split ONCE: each thread takes one 8-deep group of A and one of B from the ring slot (unit-stride ds_read_b32 down the
+// k rows), splits them and writes the fp16 hi / lo planes K-CONTIGUOUS into a second, double-buffered region ([row][32 k] halves, the
+// four 16-byte chunks of a row XOR-swizzled by (row >> 2) & 3); the matrix pass reads a fragment as ONE ds_read_b128 per plane and
+// issues no vector arithmetic at all.  Per wavefront and k-step: 16 + 12 LDS reads, ~30 vector instructions, 12 matrix instructions.
+// One barrier per k-step still: iteration t splits k-step t (landed: its DMA was issued two iterations ago) while it multiplies
+// k-step t - 1 (split in the iteration before), and re-issues the ring slot the previous split pass emptied.
+// LDS: 3 x 32 KB ring + 2 x 32 KB planes = 160 KB, the whole CU (gfx950's addressable maximum).
+// ---------------------------------------------------------------------------------------------
+constexpr int kR128PlaneBytes = 128 * 64;  // one fp16 plane of one operand: 128 rows x 32 k
+constexpr size_t ring128s_bytes() { return ring128_bytes() + (size_t)2 * 4 * kR128PlaneBytes; }
+
+__device__ __forceinline__ void gemm_ring128s_tile(const GemmArgs& g, const int bx, const int by) {
+  constexpr int TS = 128, S = kR128Stages;
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [S][A | B][32 k][128] fp32, then [2][A hi | A lo | B hi | B lo][128][32] fp16
+  char* const planes = reinterpret_cast<char*>(lds) + ring128_bytes();
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, hh = lane >> 5;
+  const int ri = wave >> 1, cj = wave & 1;
+  const int m0 = by * TS, n0 = bx * TS;
+  const int m_real = g.ones_row ? g.M - 1 : g.M;
+  const int nst = (g.K + 31) >> 5;
+  const float rsa = scale_from_amax(g.sa_dyn, g.sa), rsb = scale_from_amax(g.sb_dyn, g.sb);
+  const int kl = 4 * wave + (lane >> 5), il = (lane & 31) * 4;
+  const float* pa = g.A + (size_t)kl * g.lda + min(m0 + il, m_real - 4);
+  const float* pb = g.B + (size_t)kl * g.ldb + min(n0 + il, g.N - 4);
+  const size_t a2 = (size_t)2 * g.lda, b2 = (size_t)2 * g.ldb, a32 = (size_t)32 * g.lda, b32 = (size_t)32 * g.ldb;
+  const bool k_tail = (g.K & 31) != 0;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds) + (unsigned)wave * 2048u;
+  auto issue = [&](const int t) {
+    const unsigned slot = lds0 + (unsigned)(t % S) * (2u * kR128Tile * 4u);
+    const bool z0 = k_tail && 32 * t + kl >= g.K, z1 = k_tail && 32 * t + kl + 2 >= g.K;
+#if defined(LIPASR_R128_PROBE) && LIPASR_R128_PROBE == 3   // (timing probes, never shipped: 1 no arithmetic, 2 no operand traffic after the prologue, 3 every DMA from one hot line)
+    dma16(g.zeros, slot); dma16(g.zeros, slot + 1024u); dma16(g.zeros, slot + kR128Tile * 4u); dma16(g.zeros, slot + kR128Tile * 4u + 1024u);
+    (void)z0; (void)z1;
+#else
+    dma16(z0 ? g.zeros : pa, slot);
+    dma16(z1 ? g.zeros : pa + a2, slot + 1024u);
+    dma16(z0 ? g.zeros : pb, slot + kR128Tile * 4u);
+    dma16(z1 ? g.zeros : pb + b2, slot + kR128Tile * 4u + 1024u);
+#endif
+    pa += a32;
+    pb += b32;
+  };
+  for (int t = 0; t < min(2, nst); ++t) issue(t);
+  // split pass: this thread's group = rows k = 8 sc .. 8 sc + 7 of column si, of A and of B
+  const int si = 64 * (wave & 1) + lane, sc = wave >> 1;
+  const unsigned sp_off = (unsigned)si * 64u + (unsigned)((sc ^ ((si >> 2) & 3)) << 4);
+  const int il_ones = (g.ones_row && g.M - 1 >= m0 && g.M - 1 < m0 + TS) ? g.M - 1 - m0 : -1;  // the all-ones row of op(A) (bias gradients): patched into the slot
+  // matrix pass: fragment (row, chunk c = 2 cc + hh) of a plane
+  const int row_a = 32 * ri + r, row_b = 64 * cj + r;
+  unsigned off_a[2], off_b[2];
+#pragma unroll
+  for (int cc = 0; cc < 2; ++cc) {
+    off_a[cc] = (unsigned)row_a * 64u + (unsigned)(((2 * cc + hh) ^ ((row_a >> 2) & 3)) << 4);
+    off_b[cc] = (unsigned)row_b * 64u + (unsigned)(((2 * cc + hh) ^ ((row_b >> 2) & 3)) << 4);
+  }
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) { acc0[q] = 0.0f; acc1[q] = 0.0f; }
+  auto k_loop = [&](auto unit_a) {
+    constexpr bool UA = decltype(unit_a)::value;
+    for (int t = 0; t <= nst; ++t) {
+      if (t < nst) {  // this wavefront's part of k-step t has landed (k-step t + 1 may still be in flight: four DMA instructions)
+        if (t + 1 < nst) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (il_ones >= 0 && lane < 4) lds[(t % S) * 2 * kR128Tile + (4 * wave + lane) * TS + il_ones] = 1.0f;  // (this wavefront's own four k rows)
+      }
+      __syncthreads();  // k-step t is in its ring slot; the split pass of t - 1 and the matrix pass of t - 2 are over everywhere
+#if !defined(LIPASR_R128_PROBE) || LIPASR_R128_PROBE != 2
+      if (t + 2 < nst) issue(t + 2);  // into the slot the split pass of t - 1 emptied
+#endif
+#if !defined(LIPASR_R128_PROBE) || (LIPASR_R128_PROBE != 1 && LIPASR_R128_PROBE != 3)
+      if (t < nst) {
+        const float* Ra = lds + (t % S) * 2 * kR128Tile + (8 * sc) * TS + si;
+        char* P = planes + (t & 1) * 4 * kR128PlaneBytes + sp_off;
+        float av[8], bv[8];
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) {
+          av[s8] = Ra[s8 * TS];
+          bv[s8] = Ra[kR128Tile + s8 * TS];
+        }
+        f16x8 h, l;
+        split8<UA>(av, rsa, h, l);
+        *reinterpret_cast<f16x8*>(P) = h;
+        *reinterpret_cast<f16x8*>(P + kR128PlaneBytes) = l;
+        split8<false>(bv, rsb, h, l);
+        *reinterpret_cast<f16x8*>(P + 2 * kR128PlaneBytes) = h;
+        *reinterpret_cast<f16x8*>(P + 3 * kR128PlaneBytes) = l;
+      }
+      if (t >= 1) {
+        const char* P = planes + ((t - 1) & 1) * 4 * kR128PlaneBytes;
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+          const f16x8 ah = *reinterpret_cast<const f16x8*>(P + off_a[cc]);
+          const f16x8 al = *reinterpret_cast<const f16x8*>(P + kR128PlaneBytes + off_a[cc]);
+          const f16x8 b0h = *reinterpret_cast<const f16x8*>(P + 2 * kR128PlaneBytes + off_b[cc]);
+          const f16x8 b0l = *reinterpret_cast<const f16x8*>(P + 3 * kR128PlaneBytes + off_b[cc]);
+          const f16x8 b1h = *reinterpret_cast<const f16x8*>(P + 2 * kR128PlaneBytes + off_b[cc] + 32 * 64);
+          const f16x8 b1l = *reinterpret_cast<const f16x8*>(P + 3 * kR128PlaneBytes + off_b[cc] + 32 * 64);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b0h, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b1h, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b0l, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b1l, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b0h, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b1h, acc1, 0, 0, 0);
+        }
+      }
+#endif
+    }
+  };
+  if (rsa == 1.0f) k_loop(std::true_type{});
+  else k_loop(std::false_type{});
+  const float un = 1.0f / (rsa * rsb);
+  const int gn0 = n0 + 64 * cj + r, gn1 = gn0 + 32;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int gm = m0 + 32 * ri + (q & 3) + 8 * (q >> 2) + 4 * hh;
+    if (gm >= g.M) continue;
+    float* crow = (g.ones_row && gm == g.M - 1) ? g.extra_out : g.C + (size_t)gm * g.ldc;
+    if (gn0 < g.N) crow[gn0] = acc0[q] * un;
+    if (gn1 < g.N) crow[gn1] = acc1[q] * un;
+  }
+}
+
 // the grouped weight-gradient launch in arithmetic mode 2: every problem that is ring_legal on the LDS-DMA ring tile, the others
 // (the 64 x 10 output layer: its extent is no multiple of 4) on the register-staged tile
 __global__ __launch_bounds__(512) void gemm_ring_grouped_kernel(GemmGroup grp) {
@@ -1405,18 +1535,20 @@ __global__ __launch_bounds__(512) void gemm_ring_grouped_kernel(GemmGroup grp) {
   while (p + 1 < grp.n && (int)blockIdx.x >= grp.tile_start[p + 1]) ++p;
   const GemmArgs& g = grp.g[p];
   const int local = blockIdx.x - grp.tile_start[p];
-  const int ts = g.ring == 2 ? 128 : 64;
+  const int ts = g.ring >= 2 ? 128 : 64;
   const int ntx = (g.N + ts - 1) / ts, nty = (g.M + ts - 1) / ts;
   int bx = local % ntx, by = local / ntx;
   if (g.xcd_map && (grp.tile_start[p] & 7) == 0) xcd_tile(local, ntx, nty, bx, by);
-  if (g.ring == 2) gemm_ring128_tile(g, bx, by);
+  if (g.ring == 2) gemm_ring128s_tile(g, bx, by);
+  else if (g.ring == 3) gemm_ring128_tile(g, bx, by);
   else if (g.ring) gemm_ring_tile<1, 1>(g, bx, by, nty);
   else gemm_lds_tile<1, 1, 2, kLdsBKMax>(g, bx, by, nty);
 }
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 // amode / bmode: 1 = the operand is k-major in memory (P[k ld + i])
-static int g_ring_tile = 2;  // weight-gradient group: 2 = the 128 x 128 two-accumulator ring tile, 1 = the 64 x 64 ring tile (lipasr_debug_gemm_mode bit 6)
+static int g_ring_tile = 2;  // weight-gradient group: 2 = the 128 x 128 tile with the split pass, 3 = the 128 x 128 tile that splits per fragment (lipasr_debug_gemm_mode
+                             // bit 7), 1 = the 64 x 64 ring tile (bit 6)
 static int g_no_ring = 0;  // lipasr_debug_gemm_mode bit 5: arithmetic mode 2 on the register-staged tiles only (A/B knob)
 static bool ring_legal(int amode, int bmode, const GemmArgs& g) {
   if (g_no_ring || g.bf16 != 2 || g.M < 64 || g.N < 64 || g.K < 32) return false;
@@ -1454,7 +1586,7 @@ static int launch_gemm_group_tn(const GemmArgs* gs, int n, hipStream_t st) {
     // 128 x 128 tiles (one workgroup per CU, half the operand traffic per flop, two accumulators per wavefront) where they fill the CUs
     // the launch may use: the reference's model makes 109 of them -- 57 against 77 us on 128 CUs, 54 against 44 us on 256 (round 5)
     int ring_tile = g_ring_tile;
-    if (ring_tile == 2 && lds_tiles && ar == 2) {
+    if (ring_tile >= 2 && lds_tiles && ar == 2) {
       long n128 = 0;
       for (int q = 0; q < kMaxGroup && done + q < n; ++q)
         if (ring_legal(1, 1, gs[done + q])) n128 += (long)((gs[done + q].N + 127) / 128) * ((gs[done + q].M + 127) / 128);
@@ -1470,20 +1602,29 @@ static int launch_gemm_group_tn(const GemmArgs* gs, int n, hipStream_t st) {
       grp.g[k] = g;
       // arithmetic mode 2: the 128 x 128 two-accumulator ring tile for every problem it can take (g_ring_tile 1: the 64 x 64 ring tile)
       if (lds_tiles && ar == 2 && ring_legal(1, 1, g)) { grp.g[k].ring = ring_tile; any_ring = true; }
-      const int tp = grp.g[k].ring == 2 ? 128 : ts;
+      const int tp = grp.g[k].ring >= 2 ? 128 : ts;
       grp.tile_start[k] = tiles;
       tiles += ((g.N + tp - 1) / tp) * ((g.M + tp - 1) / tp);
     }
     grp.n = k;
     grp.tile_start[k] = tiles;
     if (any_ring) {
-      const size_t lds_r = std::max(ring_gemm_bytes(), ring_tile == 2 ? ring128_bytes() : (size_t)0);
-      static bool attr_set_dev[16] = {}; int attr_dev = 0; (void)hipGetDevice(&attr_dev); bool& attr_set = attr_set_dev[attr_dev & 15];
-      if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring_grouped_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)std::max(ring_gemm_bytes(), ring128_bytes()));
-        attr_set = true;
+      // dynamic LDS the kernel may ask for, set once per device: 160 KB (the split-pass tile: the whole CU) where the device grants it
+      static int attr_dev_max[16] = {}; int attr_dev = 0; (void)hipGetDevice(&attr_dev); int& attr_max = attr_dev_max[attr_dev & 15];
+      if (!attr_max) {
+        const void* fn = reinterpret_cast<const void*>(gemm_ring_grouped_kernel);
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring128s_bytes()) == hipSuccess) attr_max = (int)ring128s_bytes();
+        else {
+          (void)hipGetLastError();
+          (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(ring_gemm_bytes(), ring128_bytes()));
+          attr_max = (int)std::max(ring_gemm_bytes(), ring128_bytes());
+        }
       }
+      if (ring_tile == 2 && (size_t)attr_max < ring128s_bytes()) {  // (never seen on gfx950)
+        ring_tile = 3;
+        for (int q = 0; q < k; ++q) if (grp.g[q].ring == 2) grp.g[q].ring = 3;
+      }
+      const size_t lds_r = std::max(ring_gemm_bytes(), ring_tile == 2 ? ring128s_bytes() : ring_tile == 3 ? ring128_bytes() : (size_t)0);
       hipLaunchKernelGGL(gemm_ring_grouped_kernel, dim3(tiles), dim3(512), lds_r, st, grp);
     } else if (lds_tiles) {
       constexpr size_t lds_b = lds_gemm_bytes(kLdsBKMax);
@@ -2068,12 +2209,12 @@ using namespace lipasr;
 extern "C" {
 
 int lipasr_debug_gemm_mode(int mode) {
-  g_gemm_mode = mode & 3;  // (bits: 0-1 kernel choice, 2 split dW_0, 3 grouped launch on fragment tiles, 4 XCD-aware tile map, 5 no LDS-DMA ring, 6 64 x 64 ring tile for the weight gradients)
+  g_gemm_mode = mode & 3;  // (bits: 0-1 kernel choice, 2 split dW_0, 3 grouped launch on fragment tiles, 4 XCD-aware tile map, 5 no LDS-DMA ring, 6 64 x 64 ring tile for the weight gradients, 7 the 128 x 128 tile without the split pass)
   g_split_dw0 = (mode >> 2) & 1;
   g_group_lds = ((mode >> 3) & 1) ? 0 : 1;
   g_xcd_map = (mode >> 4) & 1;
   g_no_ring = (mode >> 5) & 1;
-  g_ring_tile = ((mode >> 6) & 1) ? 1 : 2;
+  g_ring_tile = ((mode >> 6) & 1) ? 1 : ((mode >> 7) & 1) ? 3 : 2;
   return LIPASR_OK;
 }
 

@@ -5,8 +5,10 @@ for kv in "$@"; do export "$kv"; done
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 out=$R/gpurun_out/pmc2_$tag
+PRE=--pre-extracted
+if [ "$PMC_CFG3" = "1" ]; then PRE=; fi   # PMC_CFG3=1: the headline configuration (the classifier on its 128-CU share)
 rm -rf $out
-rocprofv3 --kernel-trace --pmc $ctrs -d $out --output-format csv -- python3 $R/bench.py --pre-extracted --steps 12 --warmup 4 --skip-cpu-baseline --skip-other-configs --skip-b512 > $R/gpurun_out/pmc2_$tag.log 2>&1
+rocprofv3 --kernel-trace --pmc $ctrs -d $out --output-format csv -- python3 $R/bench.py $PRE --steps 12 --warmup 4 --skip-cpu-baseline --skip-other-configs --skip-b512 > $R/gpurun_out/pmc2_$tag.log 2>&1
 python3 - "$out" > $R/gpurun_out/pmc2_$tag.txt <<'PY'
 import csv, glob, sys, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
