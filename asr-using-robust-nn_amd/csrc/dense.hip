@@ -1411,6 +1411,10 @@ __device__ __forceinline__ void gemm_ring128_tile(const GemmArgs& g, const int b
 // k-step t - 1 (split in the iteration before), and re-issues the ring slot the previous split pass emptied.
 // LDS: 3 x 32 KB ring + 2 x 32 KB planes = 160 KB, the whole CU (gfx950's addressable maximum).
 // ---------------------------------------------------------------------------------------------
+#ifndef LIPASR_R128_LOADERS
+#define LIPASR_R128_LOADERS 4
+#endif
+constexpr int kR128Loaders = LIPASR_R128_LOADERS;  // 1, 2 or 4
 constexpr int kR128PlaneBytes = 128 * 64;  // one fp16 plane of one operand: 128 rows x 32 k
 constexpr size_t ring128s_bytes() { return ring128_bytes() + (size_t)2 * 4 * kR128PlaneBytes; }
 
@@ -1426,32 +1430,60 @@ __device__ __forceinline__ void gemm_ring128s_tile(const GemmArgs& g, const int 
   const int m_real = g.ones_row ? g.M - 1 : g.M;
   const int nst = (g.K + 31) >> 5;
   const float rsa = scale_from_amax(g.sa_dyn, g.sa), rsb = scale_from_amax(g.sb_dyn, g.sb);
-  const int kl = 4 * wave + (lane >> 5), il = (lane & 31) * 4;
-  const float* pa = g.A + (size_t)kl * g.lda + min(m0 + il, m_real - 4);
-  const float* pb = g.B + (size_t)kl * g.ldb + min(n0 + il, g.N - 4);
-  const size_t a2 = (size_t)2 * g.lda, b2 = (size_t)2 * g.ldb, a32 = (size_t)32 * g.lda, b32 = (size_t)32 * g.ldb;
-  const bool k_tail = (g.K & 31) != 0;
-  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds) + (unsigned)wave * 2048u;
-  auto issue = [&](const int t) {
-    const unsigned slot = lds0 + (unsigned)(t % S) * (2u * kR128Tile * 4u);
-    const bool z0 = k_tail && 32 * t + kl >= g.K, z1 = k_tail && 32 * t + kl + 2 >= g.K;
+  const int il_ones = (g.ones_row && g.M - 1 >= m0 && g.M - 1 < m0 + TS) ? g.M - 1 - m0 : -1;  // the all-ones row of op(A) (bias gradients): patched into the slot
+  // kR128Loaders extra wavefronts are LOADERS: they issue the 32 DMA instructions of a k-step (16 pieces of two k rows per operand) while the
+  // eight others split and multiply.  With every wavefront issuing its own four pieces right behind the barrier each of them sat ~800
+  // cycles of a ~2800-cycle k-step in the address path (s_memtime), the vector and matrix pipes idle meanwhile; a single wavefront gets a
+  // piece accepted every ~130 cycles and the path itself takes ~64 per piece (16 B per cycle and CU), so it takes two to keep it busy.
+  if (wave >= 8) {
+    const int L = wave - 8;
+    constexpr int NQ = 32 / kR128Loaders;  // pieces per loader and k-step: piece q -> operand q / (NQ / 2), piece index j = kR128Loaders (q % (NQ / 2)) + L
+    const float* src[NQ];
+    int krow[NQ];
+    unsigned dst[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int op = q / (NQ / 2), j = kR128Loaders * (q % (NQ / 2)) + L;
+      krow[q] = 2 * j + (lane >> 5);
+      const int c = (lane & 31) * 4;
+      src[q] = op ? g.B + (size_t)krow[q] * g.ldb + min(n0 + c, g.N - 4) : g.A + (size_t)krow[q] * g.lda + min(m0 + c, m_real - 4);
+      dst[q] = (unsigned)op * (unsigned)(kR128Tile * 4) + (unsigned)j * 1024u;
+    }
+    const size_t a32 = (size_t)32 * g.lda, b32 = (size_t)32 * g.ldb;
+    const bool k_tail = (g.K & 31) != 0;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds);
+    auto issue = [&](const int t) {
+      const unsigned slot = lds0 + (unsigned)(t % S) * (2u * kR128Tile * 4u);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
 #if defined(LIPASR_R128_PROBE) && LIPASR_R128_PROBE == 3   // (timing probes, never shipped: 1 no arithmetic, 2 no operand traffic after the prologue, 3 every DMA from one hot line)
-    dma16(g.zeros, slot); dma16(g.zeros, slot + 1024u); dma16(g.zeros, slot + kR128Tile * 4u); dma16(g.zeros, slot + kR128Tile * 4u + 1024u);
-    (void)z0; (void)z1;
+        dma16(g.zeros, slot + dst[q]);
 #else
-    dma16(z0 ? g.zeros : pa, slot);
-    dma16(z1 ? g.zeros : pa + a2, slot + 1024u);
-    dma16(z0 ? g.zeros : pb, slot + kR128Tile * 4u);
-    dma16(z1 ? g.zeros : pb + b2, slot + kR128Tile * 4u + 1024u);
+        dma16((k_tail && 32 * t + krow[q] >= g.K) ? g.zeros : src[q], slot + dst[q]);
 #endif
-    pa += a32;
-    pb += b32;
-  };
-  for (int t = 0; t < min(2, nst); ++t) issue(t);
+        src[q] += q < NQ / 2 ? a32 : b32;
+      }
+    };
+    for (int t = 0; t < min(2, nst); ++t) issue(t);
+    for (int t = 0; t <= nst; ++t) {
+      if (t < nst) {  // this loader's pieces of k-step t have landed (those of t + 1 may still be in flight)
+        if (t + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQ) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (il_ones >= 0 && lane < NQ) {  // the ones row, in the k rows this loader brought: A pieces j = kR128Loaders (lane / 2) + L, row lane & 1
+          const int k = 2 * (kR128Loaders * (lane >> 1) + L) + (lane & 1);
+          lds[(t % S) * 2 * kR128Tile + k * TS + il_ones] = 1.0f;
+        }
+      }
+      __syncthreads();
+#if !defined(LIPASR_R128_PROBE) || LIPASR_R128_PROBE != 2
+      if (t + 2 < nst) issue(t + 2);  // into the slot the split pass of t - 1 emptied
+#endif
+    }
+    return;  // (the barriers count the wavefronts that are left; there are none behind the loop)
+  }
   // split pass: this thread's group = rows k = 8 sc .. 8 sc + 7 of column si, of A and of B
   const int si = 64 * (wave & 1) + lane, sc = wave >> 1;
   const unsigned sp_off = (unsigned)si * 64u + (unsigned)((sc ^ ((si >> 2) & 3)) << 4);
-  const int il_ones = (g.ones_row && g.M - 1 >= m0 && g.M - 1 < m0 + TS) ? g.M - 1 - m0 : -1;  // the all-ones row of op(A) (bias gradients): patched into the slot
   // matrix pass: fragment (row, chunk c = 2 cc + hh) of a plane
   const int row_a = 32 * ri + r, row_b = 64 * cj + r;
   unsigned off_a[2], off_b[2];
@@ -1466,15 +1498,7 @@ __device__ __forceinline__ void gemm_ring128s_tile(const GemmArgs& g, const int 
   auto k_loop = [&](auto unit_a) {
     constexpr bool UA = decltype(unit_a)::value;
     for (int t = 0; t <= nst; ++t) {
-      if (t < nst) {  // this wavefront's part of k-step t has landed (k-step t + 1 may still be in flight: four DMA instructions)
-        if (t + 1 < nst) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (il_ones >= 0 && lane < 4) lds[(t % S) * 2 * kR128Tile + (4 * wave + lane) * TS + il_ones] = 1.0f;  // (this wavefront's own four k rows)
-      }
-      __syncthreads();  // k-step t is in its ring slot; the split pass of t - 1 and the matrix pass of t - 2 are over everywhere
-#if !defined(LIPASR_R128_PROBE) || LIPASR_R128_PROBE != 2
-      if (t + 2 < nst) issue(t + 2);  // into the slot the split pass of t - 1 emptied
-#endif
+      __syncthreads();  // k-step t is in its ring slot (the loaders waited for it); the split pass of t - 1 and the matrix pass of t - 2 are over everywhere
 #if !defined(LIPASR_R128_PROBE) || (LIPASR_R128_PROBE != 1 && LIPASR_R128_PROBE != 3)
       if (t < nst) {
         const float* Ra = lds + (t % S) * 2 * kR128Tile + (8 * sc) * TS + si;
@@ -1530,7 +1554,7 @@ __device__ __forceinline__ void gemm_ring128s_tile(const GemmArgs& g, const int 
 
 // the grouped weight-gradient launch in arithmetic mode 2: every problem that is ring_legal on the LDS-DMA ring tile, the others
 // (the 64 x 10 output layer: its extent is no multiple of 4) on the register-staged tile
-__global__ __launch_bounds__(512) void gemm_ring_grouped_kernel(GemmGroup grp) {
+__global__ __launch_bounds__(512 + 64 * kR128Loaders) void gemm_ring_grouped_kernel(GemmGroup grp) {
   int p = 0;
   while (p + 1 < grp.n && (int)blockIdx.x >= grp.tile_start[p + 1]) ++p;
   const GemmArgs& g = grp.g[p];
@@ -1539,10 +1563,227 @@ __global__ __launch_bounds__(512) void gemm_ring_grouped_kernel(GemmGroup grp) {
   const int ntx = (g.N + ts - 1) / ts, nty = (g.M + ts - 1) / ts;
   int bx = local % ntx, by = local / ntx;
   if (g.xcd_map && (grp.tile_start[p] & 7) == 0) xcd_tile(local, ntx, nty, bx, by);
-  if (g.ring == 2) gemm_ring128s_tile(g, bx, by);
-  else if (g.ring == 3) gemm_ring128_tile(g, bx, by);
+  if (g.ring == 2) { gemm_ring128s_tile(g, bx, by); return; }
+  if (threadIdx.x >= 512) return;  // (the loader wavefronts of the split-pass tile: the other tiles are eight wavefronts)
+  if (g.ring == 3) gemm_ring128_tile(g, bx, by);
   else if (g.ring) gemm_ring_tile<1, 1>(g, bx, by, nty);
   else gemm_lds_tile<1, 1, 2, kLdsBKMax>(g, bx, by, nty);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The exchange-epilogue GEMMs of arithmetic mode 2 on 128 x 64 tiles (round 5): forward (A = activations, row-major; B = kernel,
+// k-major) and input-gradient (B = kernel, K-contiguous) launches whose 64 x 64 tiling would put two or more workgroups on every CU
+// of the plan's share.  What bounds the ring kernels on a CU share is the LDS-DMA fill rate of a CU (~32 GB/s: probe 3 of the
+// weight-gradient tile above), so what counts is bytes per CU: a 128 x 64 tile moves 24 KB per k-step for the work of two 64 x 64
+// tiles (32 KB).  Same split pass as the weight-gradient tile: every thread splits one 8-deep group of A (and the first 256 threads
+// one of B) from the ring slot into K-contiguous fp16 planes, wavefront (ri, cj) multiplies the 32 x 32 output block (32 ri, 32 cj)
+// over the whole k-step from four ds_read_b128 per 16-deep chunk; no K halves to add up.  Ring of three k-steps (72 KB) + two plane
+// buffers (48 KB) + the epilogue's statistics: one workgroup per CU.  The epilogue is lds_tile_epilogue's exchange branch on four
+// 32-row passes: the workgroup contributes ONE row tile of 128 rows to its column block's exchange.
+// ---------------------------------------------------------------------------------------------
+constexpr int kR2TileA = 128 * 32, kR2TileB = 64 * 32;            // floats of one k-step's operand tiles
+constexpr int kR2Slot = kR2TileA + kR2TileB;                       // 24 KB
+constexpr int kR2Stages = 3;
+constexpr int kR2PlaneA = 128 * 64, kR2PlaneB = 64 * 64;           // bytes of one fp16 plane
+constexpr int kR2Planes = 2 * kR2PlaneA + 2 * kR2PlaneB;           // one buffer: A hi | A lo | B hi | B lo (24 KB)
+constexpr size_t ring2_bytes() { return (size_t)kR2Stages * kR2Slot * sizeof(float) + 2 * (size_t)kR2Planes + (size_t)8 * 16 * 8 * sizeof(float); }
+#ifndef LIPASR_R2_LOADERS
+#define LIPASR_R2_LOADERS 4
+#endif
+constexpr int kR2Loaders = LIPASR_R2_LOADERS;  // 1, 2, 3, 4, 6 or 8: divides the 24 pieces of a k-step
+
+template <int BMODE>
+__device__ __forceinline__ void gemm_ring2_tile(const GemmArgs& g, const int bx, const int by, const int n_row_tiles) {
+  constexpr int S = kR2Stages;
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [S][A 128x32 | B 64x32] fp32, [2] plane buffers, stat
+  char* const planes = reinterpret_cast<char*>(lds + S * kR2Slot);
+  float* const stat = reinterpret_cast<float*>(planes + 2 * kR2Planes);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, hh = lane >> 5;
+  const int ri = wave >> 1, cj = wave & 1;
+  const int m0 = by * 128, n0 = bx * 64;
+  const int nst = (g.K + 31) >> 5;
+  const unsigned xtag = xc_tag<64>(XcView{g.xc_gran, g.xc_ctrl, g.xc_err, g.xc_rt_max}, bx);
+  const float rsa = scale_from_amax(g.sa_dyn, g.sa), rsb = scale_from_amax(g.sb_dyn, g.sb);
+  if (g.amax_zero && bx == 0 && by == 0) amax_clear(g.amax_zero);
+  // kR2Loaders extra wavefronts are loaders (see the weight-gradient tile): the 24 pieces of a k-step -- 16 of 8 rows of the A tile (the eight
+  // 16-byte chunks of a row XOR-swizzled through the source address as in the 64 x 64 ring tile), 8 of the B tile -- dealt round-robin
+  if (wave >= 8) {
+    const int L = wave - 8;
+    constexpr int NQ = 24 / kR2Loaders;
+    const float* src[NQ];
+    int koff[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int j = kR2Loaders * q + L;  // piece 0 .. 23
+      if (j < 16) {
+        const int row = 8 * j + (lane >> 3);
+        koff[q] = 4 * ((lane & 7) ^ ((row >> 1) & 7));
+        src[q] = g.A + (size_t)min(m0 + row, g.M - 1) * g.lda + koff[q];
+      } else if (BMODE == 1) {
+        koff[q] = 4 * (j - 16) + (lane >> 4);
+        src[q] = g.B + (size_t)koff[q] * g.ldb + min(n0 + (lane & 15) * 4, g.N - 4);
+      } else {
+        const int br = 8 * (j - 16) + (lane >> 3);
+        koff[q] = 4 * ((lane & 7) ^ ((br >> 1) & 7));
+        src[q] = g.B + (size_t)min(n0 + br, g.N - 1) * g.ldb + koff[q];
+      }
+    }
+    const size_t sb_step = BMODE == 1 ? (size_t)32 * g.ldb : (size_t)32;
+    const bool k_tail = (g.K & 31) != 0;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds);
+    auto issue = [&](const int t) {
+      const unsigned slot = lds0 + (unsigned)(t % S) * (unsigned)(kR2Slot * 4);
+      const bool last = k_tail && t == nst - 1;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        dma16((last && 32 * t + koff[q] >= g.K) ? g.zeros : src[q], slot + (unsigned)(kR2Loaders * q + L) * 1024u);
+        src[q] += (kR2Loaders * q + L) < 16 ? (size_t)32 : sb_step;
+      }
+    };
+    for (int t = 0; t < min(2, nst); ++t) issue(t);
+    for (int t = 0; t <= nst; ++t) {
+      if (t < nst) {
+        if (t + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQ) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __syncthreads();
+      if (t + 2 < nst) issue(t + 2);  // into the slot the split pass of t - 1 emptied
+    }
+    return;  // (the barriers of the epilogue count the wavefronts that are left)
+  }
+  // split pass: row si = 64 (w & 1) + lane, chunk sc = w >> 1 of A; wavefronts 0 .. 3 also row / column `lane`, chunk w of B
+  const int si = 64 * (wave & 1) + lane, sc = wave >> 1;
+  const unsigned spa = (unsigned)si * 64u + (unsigned)((sc ^ ((si >> 2) & 3)) << 4);
+  const unsigned spb = (unsigned)lane * 64u + (unsigned)(((wave & 3) ^ ((lane >> 2) & 3)) << 4);
+  // matrix pass: fragment (row, chunk 2 cc + hh)
+  const int row_a = 32 * ri + r, row_b = 32 * cj + r;
+  unsigned off_a[2], off_b[2];
+#pragma unroll
+  for (int cc = 0; cc < 2; ++cc) {
+    off_a[cc] = (unsigned)row_a * 64u + (unsigned)(((2 * cc + hh) ^ ((row_a >> 2) & 3)) << 4);
+    off_b[cc] = (unsigned)(2 * kR2PlaneA) + (unsigned)row_b * 64u + (unsigned)(((2 * cc + hh) ^ ((row_b >> 2) & 3)) << 4);
+  }
+  f32x16 acc;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+  auto k_loop = [&](auto unit_a) {
+    constexpr bool UA = decltype(unit_a)::value;
+    for (int t = 0; t <= nst; ++t) {
+      __syncthreads();  // k-step t is in its ring slot (the loaders waited for it); the split pass of t - 1 and the matrix pass of t - 2 are over everywhere
+      if (t < nst) {
+        const float* Rs = lds + (t % S) * kR2Slot;
+        char* P = planes + (t & 1) * kR2Planes;
+        float v[8];
+        f16x8 h, l;
+        ring_frag<0>(Rs, si, sc >> 1, sc & 1, v);
+        split8<UA>(v, rsa, h, l);
+        *reinterpret_cast<f16x8*>(P + spa) = h;
+        *reinterpret_cast<f16x8*>(P + kR2PlaneA + spa) = l;
+        if (wave < 4) {
+          ring_frag<BMODE>(Rs + kR2TileA, lane, wave >> 1, wave & 1, v);
+          split8<false>(v, rsb, h, l);
+          *reinterpret_cast<f16x8*>(P + 2 * kR2PlaneA + spb) = h;
+          *reinterpret_cast<f16x8*>(P + 2 * kR2PlaneA + kR2PlaneB + spb) = l;
+        }
+      }
+      if (t >= 1) {
+        const char* P = planes + ((t - 1) & 1) * kR2Planes;
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+          const f16x8 ah = *reinterpret_cast<const f16x8*>(P + off_a[cc]);
+          const f16x8 al = *reinterpret_cast<const f16x8*>(P + kR2PlaneA + off_a[cc]);
+          const f16x8 bh = *reinterpret_cast<const f16x8*>(P + off_b[cc]);
+          const f16x8 bl = *reinterpret_cast<const f16x8*>(P + kR2PlaneB + off_b[cc]);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+        }
+      }
+    }
+  };
+  if (rsa == 1.0f) k_loop(std::true_type{});
+  else k_loop(std::false_type{});
+  // ---- epilogue: the exchange branch of lds_tile_epilogue on four 32-row passes
+  constexpr int TS = 64;
+  const int tcol = tid & 15, trow = tid >> 4;
+  const int c4 = tcol * 4, gn = n0 + c4;
+  const int gm4[4] = {m0 + trow, m0 + trow + 32, m0 + trow + 64, m0 + trow + 96};
+  BnxPre xpre[4];
+#pragma unroll
+  for (int p4 = 0; p4 < 4; ++p4) bnx_prefetch(g, gm4[p4], gn, xpre[p4]);
+  const float un = 1.0f / (rsa * rsb);
+  float* red = lds;  // [128][64] over the ring slots: their last reader was the split pass of k-step nst - 1, in front of the loop's last barrier
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int row = 32 * ri + (q & 3) + 8 * (q >> 2) + 4 * hh;
+    red[row * TS + 32 * cj + r] = acc[q] * un;
+  }
+  __syncthreads();
+  const int step = g.drop.step_dev ? *g.drop.step_dev : 0;
+  float val[4][4], av[4][4], c1[4] = {0.f, 0.f, 0.f, 0.f}, c2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int p4 = 0; p4 < 4; ++p4) {
+    const float4 s = *reinterpret_cast<const float4*>(red + (trow + 32 * p4) * TS + c4);
+    const float accv[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float t1, t2;
+      bnx_elem(g, step, gm4[p4] < g.M && gn + e < g.N, gm4[p4], gn + e, accv[e], xpre[p4], e, val[p4][e], av[p4][e], t1, t2);
+      c1[e] += t1;
+      c2[e] += t2;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    c1[e] += __shfl_xor(c1[e], 16, 64); c1[e] += __shfl_xor(c1[e], 32, 64);
+    c2[e] += __shfl_xor(c2[e], 16, 64); c2[e] += __shfl_xor(c2[e], 32, 64);
+  }
+  if (lane < 16) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      stat[(wave * 16 + lane) * 8 + e] = c1[e];
+      stat[(wave * 16 + lane) * 8 + 4 + e] = c2[e];
+    }
+  }
+  __syncthreads();  // (every read of `red` is done: it is carved up below)
+  float* mine = red;                                       // [2][64]
+  float* colp = red + 128;                                 // [2][64]
+  double* sbuf = reinterpret_cast<double*>(red + 256);     // [4][128]
+  double* tot = sbuf + 4 * 128;                            // [128]
+  if (tid < 2 * TS) {
+    const int which = tid / TS, col = tid % TS, l4 = col >> 2, e = col & 3;
+    float t = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) t += stat[(w * 16 + l4) * 8 + which * 4 + e];
+    mine[tid] = t;
+  }
+  __syncthreads();
+  XcView xc{g.xc_gran, g.xc_ctrl, g.xc_err, g.xc_rt_max};
+  xc_exchange<512, 64>(xc, bx, by, g.Bstat < 0 ? 0 : n_row_tiles, xtag, mine, sbuf, tot, [&]() {
+    if (g.epi != EPI_BIAS_RELU_BNX) return;
+#pragma unroll
+    for (int p4 = 0; p4 < 4; ++p4) {
+      if (gm4[p4] >= g.M) continue;
+      float* crow = g.C + (size_t)gm4[p4] * g.ldc;
+      if (gn + 3 < g.N && ((g.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(crow) & 15) == 0)) {
+        *reinterpret_cast<float4*>(crow + gn) = make_float4(val[p4][0], val[p4][1], val[p4][2], val[p4][3]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (gn + e < g.N) crow[gn + e] = val[p4][e];
+      }
+    }
+  });
+  if (tid < TS) bnx_column(g, by, n0 + tid, tid, TS, tot, colp);
+  __syncthreads();
+  bnx_finish<4>(g, step, gm4, gn, val, av, colp, TS, c4);
+}
+
+template <int BMODE>
+__global__ __launch_bounds__(512 + 64 * kR2Loaders) void gemm_ring2_kernel(GemmArgs g) {
+  gemm_ring2_tile<BMODE>(g, blockIdx.x, blockIdx.y, gridDim.y);
 }
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -1558,6 +1799,20 @@ static bool ring_legal(int amode, int bmode, const GemmArgs& g) {
   if (amode == 1 && ((m_real & 3) || m_real < 4)) return false;
   if (bmode == 1 && ((g.N & 3) || g.N < 4)) return false;
   return true;
+}
+
+// The 128 x 64 exchange tile (gemm_ring2_tile) pays where the 64 x 64 tiling would put two workgroups on (nearly) every CU of the
+// plan's share: then it halves the workgroups and moves 3/4 of the bytes per CU; with fewer tiles than that it would leave CUs idle.
+// One workgroup per CU (124 KB of LDS) and every workgroup resident (the exchange): at most `cus` tiles.
+static int g_ring2 = 1;  // lipasr_debug_gemm_mode bit 8 clears it (A/B knob)
+static long g_launch_count[2] = {0, 0};  // lipasr_debug_launch_count: 0 = launches on 128 x 64 exchange tiles, 1 = weight-gradient launches with 128 x 128 split-pass tiles
+static bool use_ring2(int bmode, const GemmArgs& g) {
+  if (!g_ring2 || g.bf16 != 2 || g.M < 128 || g.N < 64 || !ring_legal(0, bmode, g)) return false;
+  if (bmode == 0 && g.N < 64) return false;
+  int cus = g.cus;
+  if (cus <= 0) { hipDeviceProp_t prop; int dev = 0; (void)hipGetDevice(&dev); cus = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256; }
+  const long tiles = (long)((g.M + 127) / 128) * ((g.N + 63) / 64);
+  return 4 * tiles >= 3 * (long)cus && tiles <= (long)cus && (g.M + 127) / 128 <= g.xc_rt_max;
 }
 
 // arithmetic mode (GemmArgs::bf16: 0 exact fp32, 1 bf16 operands, 2 fp16 two-plane split) -> template instance
@@ -1583,8 +1838,11 @@ static int launch_gemm_group_tn(const GemmArgs* gs, int n, hipStream_t st) {
     const bool lds_tiles = g_group_lds && big >= 128 && gs[done].K >= 64;
     const int ts = lds_tiles ? 64 : 32;
     const int ar = gs[done].bf16;
-    // 128 x 128 tiles (one workgroup per CU, half the operand traffic per flop, two accumulators per wavefront) where they fill the CUs
-    // the launch may use: the reference's model makes 109 of them -- 57 against 77 us on 128 CUs, 54 against 44 us on 256 (round 5)
+    // 128 x 128 tiles (one workgroup per CU, half the operand bytes per flop, two accumulators per wavefront).  A CU takes in ~32 GB/s
+    // whatever asks (LDS-DMA or register loads), so a launch is as long as its busiest CU's bytes: one 128 x 128 tile = 1 MB, two 64 x 64
+    // tiles per CU = 1 MB as well but four per CU 2 MB.  The reference's model makes 105 + 4 tiles: with the split pass and the loader
+    // wavefronts 38-40 us on a 128-CU share (64 x 64 ring tiles: 77) and config 2's step 0.310 against 0.316 ms on all 256 CUs, where
+    // they leave 150 CUs idle -- so: whenever the tiles cover 40 % of the CUs the launch may use.
     int ring_tile = g_ring_tile;
     if (ring_tile >= 2 && lds_tiles && ar == 2) {
       long n128 = 0;
@@ -1592,7 +1850,7 @@ static int launch_gemm_group_tn(const GemmArgs* gs, int n, hipStream_t st) {
         if (ring_legal(1, 1, gs[done + q])) n128 += (long)((gs[done + q].N + 127) / 128) * ((gs[done + q].M + 127) / 128);
       int cus = gs[done].cus;
       if (cus <= 0) { hipDeviceProp_t prop; int dev = 0; (void)hipGetDevice(&dev); cus = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256; }
-      if (10 * n128 < 6 * (long)cus) ring_tile = 1;
+      if (10 * n128 < 4 * (long)cus) ring_tile = 1;
     }
     int k = 0, tiles = 0;
     bool any_ring = false;
@@ -1625,7 +1883,8 @@ static int launch_gemm_group_tn(const GemmArgs* gs, int n, hipStream_t st) {
         for (int q = 0; q < k; ++q) if (grp.g[q].ring == 2) grp.g[q].ring = 3;
       }
       const size_t lds_r = std::max(ring_gemm_bytes(), ring_tile == 2 ? ring128s_bytes() : ring_tile == 3 ? ring128_bytes() : (size_t)0);
-      hipLaunchKernelGGL(gemm_ring_grouped_kernel, dim3(tiles), dim3(512), lds_r, st, grp);
+      if (ring_tile == 2) ++g_launch_count[1];
+      hipLaunchKernelGGL(gemm_ring_grouped_kernel, dim3(tiles), dim3(ring_tile == 2 ? 512 + 64 * kR128Loaders : 512), lds_r, st, grp);  // (loader wavefronts: the split-pass tile only)
     } else if (lds_tiles) {
       constexpr size_t lds_b = lds_gemm_bytes(kLdsBKMax);
       static bool attr_set_dev[16] = {}; int attr_dev = 0; (void)hipGetDevice(&attr_dev); bool& attr_set = attr_set_dev[attr_dev & 15];  /* per device */
@@ -1702,7 +1961,18 @@ static int launch_gemm(int amode, int bmode, const GemmArgs& g, hipStream_t st) 
   }
   if (g.epi == EPI_BIAS_RELU_BNX || g.epi == EPI_DH_BNX) {  // the exchange epilogue: forward (NN) or input-gradient (NT) GEMMs only
     if (amode != 0) { set_error("gemm: the exchange epilogue needs a row-major A operand"); return LIPASR_EINVAL; }
-    if (use_lds_gemm(g.M, g.N, g.K, g.lds_min_tiles) && ring_legal(0, bmode, g)) {
+    if (use_ring2(bmode, g)) {  // 128 x 64 tiles, one workgroup per CU of the plan's share
+      ++g_launch_count[0];
+      const dim3 grid((g.N + 63) / 64, (g.M + 127) / 128);
+      static bool attr_set_dev[16] = {}; int attr_dev = 0; (void)hipGetDevice(&attr_dev); bool& attr_set = attr_set_dev[attr_dev & 15];
+      if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring2_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring2_bytes());
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring2_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring2_bytes());
+        attr_set = true;
+      }
+      if (bmode == 0) hipLaunchKernelGGL((gemm_ring2_kernel<0>), grid, dim3(512 + 64 * kR2Loaders), ring2_bytes(), st, g);
+      else hipLaunchKernelGGL((gemm_ring2_kernel<1>), grid, dim3(512 + 64 * kR2Loaders), ring2_bytes(), st, g);
+    } else if (use_lds_gemm(g.M, g.N, g.K, g.lds_min_tiles) && ring_legal(0, bmode, g)) {
       const dim3 grid((g.N + 63) / 64, (g.M + 63) / 64);
       static bool attr_set_dev[16] = {}; int attr_dev = 0; (void)hipGetDevice(&attr_dev); bool& attr_set = attr_set_dev[attr_dev & 15];
       if (!attr_set) {
@@ -2208,13 +2478,16 @@ using namespace lipasr;
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
+long lipasr_debug_launch_count(int kind) { return (kind == 0 || kind == 1) ? g_launch_count[kind] : -1; }
+
 int lipasr_debug_gemm_mode(int mode) {
-  g_gemm_mode = mode & 3;  // (bits: 0-1 kernel choice, 2 split dW_0, 3 grouped launch on fragment tiles, 4 XCD-aware tile map, 5 no LDS-DMA ring, 6 64 x 64 ring tile for the weight gradients, 7 the 128 x 128 tile without the split pass)
+  g_gemm_mode = mode & 3;  // (bits: 0-1 kernel choice, 2 split dW_0, 3 grouped launch on fragment tiles, 4 XCD-aware tile map, 5 no LDS-DMA ring, 6 64 x 64 ring tile for the weight gradients, 7 the 128 x 128 tile without the split pass, 8 no 128 x 64 exchange tiles)
   g_split_dw0 = (mode >> 2) & 1;
   g_group_lds = ((mode >> 3) & 1) ? 0 : 1;
   g_xcd_map = (mode >> 4) & 1;
   g_no_ring = (mode >> 5) & 1;
   g_ring_tile = ((mode >> 6) & 1) ? 1 : ((mode >> 7) & 1) ? 3 : 2;
+  g_ring2 = ((mode >> 8) & 1) ? 0 : 1;
   return LIPASR_OK;
 }
 

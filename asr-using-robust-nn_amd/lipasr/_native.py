@@ -121,6 +121,7 @@ PROTOTYPES = {
     "lipasr_add_noise_f32": (i32, [c_h, c_f, i32, i32, i32, f32, f32, u64, c_s]),
     "lipasr_debug_set": (i32, [c_h, i32, i32]),
     "lipasr_debug_gemm_mode": (i32, [i32]),
+    "lipasr_debug_launch_count": (C.c_long, [i32]),
     "lipasr_flag_signal": (i32, [c_h, C.c_void_p, i32, c_s]),
     "lipasr_flag_wait": (i32, [c_h, C.c_void_p, i32, i32, C.c_void_p, c_s]),
     "lipasr_debug_chain_head": (i32, [i32]),

@@ -454,8 +454,15 @@ int lipasr_debug_set(lipasr_handle_t h, int key, int value);
 /* Profiling knob: GEMM kernel choice. bits 0-1: 0 = automatic, 1 = split-K register kernel only, 2 = LDS-tiled kernel
  * wherever it is legal.  bit 2 (4): lipasr_mlp_train_fwd_bwd launches the first layer's weight gradient on its own
  * (as the data-parallel head / dw0 pair does) instead of inside the grouped launch.  bit 3 (8): the grouped weight-gradient
- * launch on 32x32 register-fragment tiles (round 2) instead of 64x64 LDS tiles. */
+ * launch on 32x32 register-fragment tiles (round 2) instead of 64x64 LDS tiles.  Round 5 (arithmetic mode 2 only): bit 4 (16) the
+ * XCD-aware tile order, bit 5 (32) no LDS-DMA ring kernels, bit 6 (64) the weight gradients on 64x64 ring tiles, bit 7 (128) on
+ * 128x128 tiles that split per fragment (no split pass), bit 8 (256) no 128x64 exchange tiles.  Same results in every setting. */
 int lipasr_debug_gemm_mode(int mode);
+
+/* Test hook: how many launches since the library was loaded took kernel family `kind` -- 0: forward / input-gradient GEMMs on
+ * 128x64 exchange tiles, 1: grouped weight-gradient launches with 128x128 split-pass tiles; -1 for an unknown kind.  (The choice
+ * depends on the plan's CU budget; tests that mean to cover those kernels check that they really ran.) */
+long lipasr_debug_launch_count(int kind);
 
 /* Profiling knob: how many of the leading (small) steps of the product chain W_m^T ... W_1^T run as ONE launch
  * (chain_head_kernel, fp32 matrix instructions): -1 = automatic (the first two steps, when their panels have <= 256 columns
