@@ -1194,7 +1194,7 @@ __device__ __forceinline__ void ring_frag(const float* __restrict__ T, const int
   }
 }
 
-template <int AMODE, int BMODE, bool X = false>
+template <int AMODE, int BMODE, bool X = false, int NL = 0>  // NL: loader wavefronts beside the eight that multiply (0: every wavefront brings its own two pieces)
 __device__ __forceinline__ void gemm_ring_tile(const GemmArgs& g, const int bx, const int by, const int n_row_tiles) {
   constexpr int TS = 64, S = kRingStages;
   extern __shared__ __attribute__((aligned(16))) float lds[];  // [S][A | B][2048]; the epilogue reuses the first 32 KB; then stat
@@ -1226,25 +1226,73 @@ __device__ __forceinline__ void gemm_ring_tile(const GemmArgs& g, const int bx, 
     pa += sa_step;
     pb += sb_step;
   };
-  const int pre = min(S - 1, nst);
-  for (int t = 0; t < pre; ++t) issue(t);
-  // the all-ones row of op(A) (bias gradient of the weight-gradient GEMMs) does not exist in memory: it is written into the slot
   const int il_ones = (AMODE == 1 && g.ones_row && g.M - 1 >= m0 && g.M - 1 < m0 + TS) ? g.M - 1 - m0 : -1;
+  if constexpr (NL > 0) {
+    // NL extra wavefronts bring the 16 pieces of a k-step (see the weight-gradient tile: a wavefront that issues LDS-DMA sits in the address
+    // path meanwhile); loader L takes the pieces of wavefronts L, L + NL, ... of both operands
+    if (wave >= 8) {
+      const int L = wave - 8;
+      constexpr int NP = 8 / NL;
+      const float* sa[NP];
+      const float* sb[NP];
+      int ka[NP], kb[NP];
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+        const int w = L + NL * q;
+        sa[q] = ring_src<AMODE>(g.A, g.lda, m0, m_real, w, lane);
+        sb[q] = ring_src<BMODE>(g.B, g.ldb, n0, g.N, w, lane);
+        ka[q] = AMODE == 1 ? 4 * w + (lane >> 4) : 4 * ((lane & 7) ^ (((8 * w + (lane >> 3)) >> 1) & 7));
+        kb[q] = BMODE == 1 ? 4 * w + (lane >> 4) : 4 * ((lane & 7) ^ (((8 * w + (lane >> 3)) >> 1) & 7));
+      }
+      const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds);
+      auto issue_l = [&](const int t) {
+        const unsigned slot = base + (unsigned)(t % S) * (2u * kRingTile * 4u);
+        const bool last = k_tail && t == nst - 1;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+          const unsigned d = slot + (unsigned)(L + NL * q) * 1024u;
+          dma16((last && 32 * t + ka[q] >= g.K) ? g.zeros : sa[q], d);
+          dma16((last && 32 * t + kb[q] >= g.K) ? g.zeros : sb[q], d + kRingTile * 4u);
+          sa[q] += sa_step;
+          sb[q] += sb_step;
+        }
+      };
+      for (int t = 0; t < min(S - 1, nst); ++t) issue_l(t);
+      for (int t = 0; t < nst; ++t) {
+        const int ahead = min(t + S - 2, nst - 1) - t;  // k-steps requested beyond t: 2 NP instructions each, completed in order
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NP) : "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (il_ones >= 0 && lane < 4 * NP) lds[(t % S) * 2 * kRingTile + (4 * (L + NL * (lane >> 2)) + (lane & 3)) * 64 + il_ones] = 1.0f;
+        __syncthreads();
+        if (t + S - 1 < nst) issue_l(t + S - 1);
+      }
+      __syncthreads();  // (the barrier in front of the epilogue)
+      return;
+    }
+  }
+  const int pre = NL > 0 ? 0 : min(S - 1, nst);
+  for (int t = 0; t < pre; ++t) issue(t);
+  // (the all-ones row of op(A) -- bias gradient of the weight-gradient GEMMs -- does not exist in memory: it is written into the slot)
   f32x16 acc;
 #pragma unroll
   for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
   auto k_loop = [&](auto unit_a) {  // (two copies of the loop: an unscaled A operand -- the activations -- splits in 12 instructions instead of 16)
     constexpr bool UA = decltype(unit_a)::value;
     for (int t = 0; t < nst; ++t) {
-      const int ahead = min(t + S - 2, nst - 1) - t;  // k-steps requested beyond t: two DMA instructions each, completed in order
-      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       float* At = lds + (t % S) * 2 * kRingTile;
-      if (il_ones >= 0 && lane < 4) At[(4 * wave + lane) * 64 + il_ones] = 1.0f;  // (this wavefront's own four k rows: they have landed)
+      if constexpr (NL == 0) {
+        const int ahead = min(t + S - 2, nst - 1) - t;  // k-steps requested beyond t: two DMA instructions each, completed in order
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (il_ones >= 0 && lane < 4) At[(4 * wave + lane) * 64 + il_ones] = 1.0f;  // (this wavefront's own four k rows: they have landed)
+      }
       __syncthreads();  // every wavefront's part of k-step t is in LDS, and everybody is done with the slot of k-step t - 1
 #if !defined(LIPASR_RING_PROBE) || LIPASR_RING_PROBE != 2   // (timing probes, never shipped: 1 = no arithmetic, 2 = no operand traffic after the prologue)
-      if (t + S - 1 < nst) issue(t + S - 1);
+      if constexpr (NL == 0) {
+        if (t + S - 1 < nst) issue(t + S - 1);
+      }
 #endif
 #if !defined(LIPASR_RING_PROBE) || LIPASR_RING_PROBE != 1
       float av[8], bv[8];
@@ -1265,11 +1313,17 @@ __device__ __forceinline__ void gemm_ring_tile(const GemmArgs& g, const int bx, 
   lds_tile_epilogue<X>(g, acc, lds, stat, bx, by, n_row_tiles, xtag);
 }
 
+#ifndef LIPASR_RING_LOADERS
+#define LIPASR_RING_LOADERS 0
+#endif
+constexpr int kRingLoaders = LIPASR_RING_LOADERS;  // 0, 1, 2 or 4 (with the exchange epilogue's 81 registers two workgroups of ten wavefronts still share a CU).
+// Measured with 2 (same box, interleaved): config 3 0.3427 against 0.3422 ms, config 2 0.3117 against 0.3108 -- two workgroups per CU already
+// overlap one's address-path time with the other's arithmetic; the loaders pay where ONE workgroup owns the CU (the tiles below).  Off.
 template <int AMODE, int BMODE, bool X = false>
-__global__ __launch_bounds__(512) void gemm_ring_kernel(GemmArgs g) {
+__global__ __launch_bounds__(512 + 64 * kRingLoaders) void gemm_ring_kernel(GemmArgs g) {
   int bx = blockIdx.x, by = blockIdx.y;
   if (g.xcd_map) xcd_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x, gridDim.y, bx, by);
-  gemm_ring_tile<AMODE, BMODE, X>(g, bx, by, gridDim.y);
+  gemm_ring_tile<AMODE, BMODE, X, kRingLoaders>(g, bx, by, gridDim.y);
 }
 
 template <int AMODE, int BMODE, int BF = 0, int BK = kLdsBKMax, bool X = false>
@@ -1672,34 +1726,46 @@ __device__ __forceinline__ void gemm_ring2_tile(const GemmArgs& g, const int bx,
     constexpr bool UA = decltype(unit_a)::value;
     for (int t = 0; t <= nst; ++t) {
       __syncthreads();  // k-step t is in its ring slot (the loaders waited for it); the split pass of t - 1 and the matrix pass of t - 2 are over everywhere
+      // Order inside a k-step (one dependent chain per wavefront, so the LDS round trips are put behind each other's shadow): the
+      // split pass's raw reads and the matrix pass's first fragments are requested together, the splits run while the fragments
+      // arrive, the second chunk's fragments are requested in front of the first chunk's matrix instructions.
+      const float* Rs = lds + (t % S) * kR2Slot;
+      const char* Pm = planes + ((t - 1) & 1) * kR2Planes;
+      float va[8], vb[8];
+      f16x8 ah, al, bh, bl;
       if (t < nst) {
-        const float* Rs = lds + (t % S) * kR2Slot;
+        ring_frag<0>(Rs, si, sc >> 1, sc & 1, va);
+        if (wave < 4) ring_frag<BMODE>(Rs + kR2TileA, lane, wave >> 1, wave & 1, vb);
+      }
+      if (t >= 1) {
+        ah = *reinterpret_cast<const f16x8*>(Pm + off_a[0]);
+        al = *reinterpret_cast<const f16x8*>(Pm + kR2PlaneA + off_a[0]);
+        bh = *reinterpret_cast<const f16x8*>(Pm + off_b[0]);
+        bl = *reinterpret_cast<const f16x8*>(Pm + kR2PlaneB + off_b[0]);
+      }
+      if (t < nst) {
         char* P = planes + (t & 1) * kR2Planes;
-        float v[8];
         f16x8 h, l;
-        ring_frag<0>(Rs, si, sc >> 1, sc & 1, v);
-        split8<UA>(v, rsa, h, l);
+        split8<UA>(va, rsa, h, l);
         *reinterpret_cast<f16x8*>(P + spa) = h;
         *reinterpret_cast<f16x8*>(P + kR2PlaneA + spa) = l;
         if (wave < 4) {
-          ring_frag<BMODE>(Rs + kR2TileA, lane, wave >> 1, wave & 1, v);
-          split8<false>(v, rsb, h, l);
+          split8<false>(vb, rsb, h, l);
           *reinterpret_cast<f16x8*>(P + 2 * kR2PlaneA + spb) = h;
           *reinterpret_cast<f16x8*>(P + 2 * kR2PlaneA + kR2PlaneB + spb) = l;
         }
       }
       if (t >= 1) {
-        const char* P = planes + ((t - 1) & 1) * kR2Planes;
-#pragma unroll
-        for (int cc = 0; cc < 2; ++cc) {
-          const f16x8 ah = *reinterpret_cast<const f16x8*>(P + off_a[cc]);
-          const f16x8 al = *reinterpret_cast<const f16x8*>(P + kR2PlaneA + off_a[cc]);
-          const f16x8 bh = *reinterpret_cast<const f16x8*>(P + off_b[cc]);
-          const f16x8 bl = *reinterpret_cast<const f16x8*>(P + kR2PlaneB + off_b[cc]);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
-        }
+        const f16x8 ah1 = *reinterpret_cast<const f16x8*>(Pm + off_a[1]);
+        const f16x8 al1 = *reinterpret_cast<const f16x8*>(Pm + kR2PlaneA + off_a[1]);
+        const f16x8 bh1 = *reinterpret_cast<const f16x8*>(Pm + off_b[1]);
+        const f16x8 bl1 = *reinterpret_cast<const f16x8*>(Pm + kR2PlaneB + off_b[1]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bl1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh1, acc, 0, 0, 0);
       }
     }
   };
@@ -1980,8 +2046,8 @@ static int launch_gemm(int amode, int bmode, const GemmArgs& g, hipStream_t st) 
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring_kernel<0, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_gemm_bytes());
         attr_set = true;
       }
-      if (bmode == 0) hipLaunchKernelGGL((gemm_ring_kernel<0, 0, true>), grid, dim3(512), ring_gemm_bytes(), st, g);
-      else hipLaunchKernelGGL((gemm_ring_kernel<0, 1, true>), grid, dim3(512), ring_gemm_bytes(), st, g);
+      if (bmode == 0) hipLaunchKernelGGL((gemm_ring_kernel<0, 0, true>), grid, dim3(512 + 64 * kRingLoaders), ring_gemm_bytes(), st, g);
+      else hipLaunchKernelGGL((gemm_ring_kernel<0, 1, true>), grid, dim3(512 + 64 * kRingLoaders), ring_gemm_bytes(), st, g);
     } else if (use_lds_gemm(g.M, g.N, g.K, g.lds_min_tiles)) {
       const dim3 grid((g.N + 63) / 64, (g.M + 63) / 64);
       constexpr size_t lds_b = lds_gemm_bytes(kLdsBKMax);
@@ -2028,7 +2094,7 @@ static int launch_gemm(int amode, int bmode, const GemmArgs& g, hipStream_t st) 
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring_kernel<A_, B_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_gemm_bytes()); \
       attr_set = true;                                                                                                                  \
     }                                                                                                                                   \
-    hipLaunchKernelGGL((gemm_ring_kernel<A_, B_>), grid, dim3(512), ring_gemm_bytes(), st, g);                                          \
+    hipLaunchKernelGGL((gemm_ring_kernel<A_, B_>), grid, dim3(512 + 64 * kRingLoaders), ring_gemm_bytes(), st, g);                                          \
   }
     if (amode == 0 && bmode == 0) LP_RING(0, 0) else if (amode == 0 && bmode == 1) LP_RING(0, 1)
     else if (amode == 1 && bmode == 0) LP_RING(1, 0) else LP_RING(1, 1)
@@ -2119,7 +2185,7 @@ static bool bnx_fits(const lipasr_mlp* m, bool forward, int M, int N, int K) {
   if (ar == 2 && lds_k) {  // the launch may take the LDS-DMA ring instance (68 KB of LDS): the smaller of the two answers
     static int ring_pc[2] = {-1, -1};
     int& rp = ring_pc[forward ? 0 : 1];
-    if (rp < 0) rp = forward ? blocks_per_cu(gemm_ring_kernel<0, 1, true>, 512, ring_gemm_bytes()) : blocks_per_cu(gemm_ring_kernel<0, 0, true>, 512, ring_gemm_bytes());
+    if (rp < 0) rp = forward ? blocks_per_cu(gemm_ring_kernel<0, 1, true>, 512 + 64 * kRingLoaders, ring_gemm_bytes()) : blocks_per_cu(gemm_ring_kernel<0, 0, true>, 512 + 64 * kRingLoaders, ring_gemm_bytes());
     per = std::min(per, rp);
   }
   const int cus = m->cu_budget > 0 ? std::min(m->cu_budget, m->n_cus) : m->n_cus;

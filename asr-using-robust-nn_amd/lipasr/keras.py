@@ -405,6 +405,8 @@ class Model:
 
         if _os.environ.get("LIPASR_FUSE_BN", "1") == "0":  # A/B knob: BatchNorm as launches of its own (the round-4 chain)
             N.check(N.lib.lipasr_mlp_set_fuse_bn(plan, 0))
+        if _os.environ.get("LIPASR_GEMM_TILES"):  # A/B knob: 64 x 64 tiles from which a GEMM takes the LDS-tiled / ring kernels (default 224; the pipeline sets 128 on a CU share)
+            N.check(N.lib.lipasr_mlp_set_gemm_tiles(plan, int(_os.environ["LIPASR_GEMM_TILES"])))
         n_params, n_state = N.sz(), N.sz()
         N.check(N.lib.lipasr_mlp_sizes(plan, C.byref(n_params), C.byref(n_state)))
         dev = self._device
