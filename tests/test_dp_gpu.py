@@ -198,7 +198,14 @@ def test_head_plus_dw0_equals_one_call(cuda):
     assert torch.isnan(m2._grads[:late]).all()           # the head leaves [dW_0 | db_0] alone
     untouched = torch.isnan(m2._grads[late:])            # the alignment pads between segments are never written
     assert int(untouched.sum()) < 32 and float(whole[late:][untouched].abs().max() if untouched.any() else 0.0) == 0.0
-    assert torch.equal(m2._grads[late:][~untouched], whole[late:][~untouched])
+    if getattr(m, "_compute_dtype", "float32") == "float16x2":
+        # arithmetic mode 2 chooses the weight-gradient tile by how many 128 x 128 tiles the GROUP makes: with layer 1 in the group
+        # they cover 40 % of the chip (128 x 128 split-pass tiles), without it they do not (64 x 64 ring tiles) -- the same sums in
+        # another fp32 order, each path bitwise reproducible in itself
+        a, b = m2._grads[late:][~untouched], whole[late:][~untouched]
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
+    else:
+        assert torch.equal(m2._grads[late:][~untouched], whole[late:][~untouched])
     m2.train_dw0(x)
     d = (m2._grads[:late] - whole[:late]).abs().max() / whole[:late].abs().max()
     assert float(d) < 2e-5, float(d)
