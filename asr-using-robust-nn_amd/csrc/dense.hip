@@ -313,6 +313,9 @@ struct XcView {
   int rt_max;
 };
 constexpr long long kXcTimeoutTicks = 200000000LL;  // 2 s of the 100 MHz wall clock
+#ifndef LIPASR_XC_POLL_SLEEP
+#define LIPASR_XC_POLL_SLEEP 6  // s_sleep units (64 cycles) between two reads of the `published` word by the one polling lane (16 / 6 / 2 measured: config 3 0.3526 / 0.3483 / 0.3490, config 2 0.3109 / 0.3104 / 0.3102)
+#endif
 
 // NT threads; CB columns per block (32: the fragment kernel, 64: the LDS-tiled kernel).  mine[2 CB]: this tile's partial sums
 // (LDS).  On return tot[2 CB] (LDS, fp64) holds the sums over all n_rt row tiles.  sbuf: LDS, (NT / (2 CB)) x 2 CB doubles.
@@ -351,7 +354,7 @@ __device__ __forceinline__ void xc_exchange(const XcView& xc, int bx, int by, in
   if (tid == 0 && n_rt > 0) {
     const long long t0 = wall_clock64();
     while (__hip_atomic_load(cw + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)n_rt) {
-      __builtin_amdgcn_s_sleep(16);
+      __builtin_amdgcn_s_sleep(LIPASR_XC_POLL_SLEEP);
       if (wall_clock64() - t0 > kXcTimeoutTicks) { __hip_atomic_store(xc.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
     }
   }
