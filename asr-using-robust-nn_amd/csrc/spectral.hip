@@ -27,6 +27,9 @@ constexpr int kMaxOrder = 64;
 constexpr int kChainRowsPerWave = 1;
 constexpr int kChainRowsPerBlock = 4 * kChainRowsPerWave;
 constexpr int kSquarings = 40;
+#ifndef LIPASR_SIGMA_WGS
+#define LIPASR_SIGMA_WGS 256  // workgroups of sigma_scale_layers_kernel (each recomputes sigma, then scales its slice of a layer)
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // chain step: P_out[r][i] = sum_j P_in[r][j] * W[i][j],  i < n_rows, j < n_in, r < R
@@ -407,6 +410,7 @@ struct LayerPtrs {
   float* W[LIPASR_MAX_LAYERS];
   int rows[LIPASR_MAX_LAYERS];
   int cols[LIPASR_MAX_LAYERS];
+  int wg_start[LIPASR_MAX_LAYERS + 1];  // sigma_scale_layers_kernel only: workgroups wg_start[l] .. wg_start[l + 1] - 1 scale layer l
 };
 
 // blockIdx.y = layer; W_l *= scales[l] (skipped when the factor is exactly 1)
@@ -531,7 +535,7 @@ __global__ __launch_bounds__(256) void sigma_scale_layers_kernel(const float* __
   }
   const double log_lambda = zero ? 0.0 : ll_s;
   if (tid == 0) {
-    const bool first = blockIdx.x == 0 && blockIdx.y == 0;
+    const bool first = blockIdx.x == 0;
     if (first && bump) *bump += 1;
     const double sigma = zero ? 0.0 : exp(0.5 * log_lambda);
     if (first && sigma_out) *sigma_out = (float)sigma;
@@ -551,23 +555,25 @@ __global__ __launch_bounds__(256) void sigma_scale_layers_kernel(const float* __
     }
   }
   __syncthreads();
-  const int l = blockIdx.y;
+  int l = 0;
+  while (l + 1 < lp.n_layers && (int)blockIdx.x >= lp.wg_start[l + 1]) ++l;
   const float s = sc_s[l];
   if (s == 1.0f) return;
   float* w = lp.W[l];
   const size_t nw = (size_t)lp.rows[l] * lp.cols[l];
-  const size_t stride = (size_t)gridDim.x * 256;
+  const size_t j = (size_t)((int)blockIdx.x - lp.wg_start[l]);
+  const size_t stride = (size_t)(lp.wg_start[l + 1] - lp.wg_start[l]) * 256;
   if ((reinterpret_cast<uintptr_t>(w) & 15) == 0) {
     const size_t n4 = nw >> 2;
     float4* w4 = reinterpret_cast<float4*>(w);
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    for (size_t i = j * 256 + threadIdx.x; i < n4; i += stride) {
       float4 x = w4[i];
       x.x *= s; x.y *= s; x.z *= s; x.w *= s;
       w4[i] = x;
     }
-    for (size_t i = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < nw; i += stride) w[i] *= s;
+    for (size_t i = (n4 << 2) + j * 256 + threadIdx.x; i < nw; i += stride) w[i] *= s;
   } else {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nw; i += stride) w[i] *= s;
+    for (size_t i = j * 256 + threadIdx.x; i < nw; i += stride) w[i] *= s;
   }
 }
 
@@ -1208,7 +1214,21 @@ int lipasr::project_product_bump(lipasr_handle_t h, float* const* Ws, const int*
       LP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sigma_scale_layers_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
       attr_set = true;
     }
-    hipLaunchKernelGGL(sigma_scale_layers_kernel, dim3(64, n_layers), dim3(256), lds, S(stream), p_final, n0, R, (double)rho, oa, lp, cs.scales,
+    // Workgroups in proportion to the layers' sizes (every one recomputes sigma first -- fp64, the same arithmetic on the same inputs --
+    // and they share the CUs' fp64 rate: 64 per layer = 384 took 23.9 us on a 128-CU share, 128 per layer 38.7, 32 per layer 26.6 because
+    // layer 1's slice got long)
+    {
+      size_t total = 0;
+      for (int l = 0; l < n_layers; ++l) total += (size_t)rows[l] * cols[l];
+      int acc_wg = 0;
+      for (int l = 0; l < n_layers; ++l) {
+        lp.wg_start[l] = acc_wg;
+        const size_t sz = (size_t)rows[l] * cols[l];
+        acc_wg += std::max(1, (int)((sz * LIPASR_SIGMA_WGS + total / 2) / total));
+      }
+      lp.wg_start[n_layers] = acc_wg;
+    }
+    hipLaunchKernelGGL(sigma_scale_layers_kernel, dim3(lp.wg_start[n_layers]), dim3(256), lds, S(stream), p_final, n0, R, (double)rho, oa, lp, cs.scales,
                        norms_out, cs.sigma, bump);
     LP_LAUNCH_CHECK();
     return LIPASR_OK;
