@@ -10,7 +10,8 @@
  *
  * lipasr_version(): 500 = round 5.  ABI history: 300 (round 3) -> round 4 added lipasr_flag_signal / lipasr_flag_wait and
  * lipasr_debug_chain_head without a bump -> 500: lipasr_flag_wait reports and keeps waiting (see its comment), plus the
- * round-5 entry points marked "(round 5)" below.
+ * round-5 entry points marked "(round 5)" below (lipasr_gemm_f16x2, lipasr_mlp_set_fuse_bn / _set_cu_budget / _exchange_errors,
+ * lipasr_debug_launch_count).
  *
  * Conventions
  *   - every function returns int: 0 = LIPASR_OK, negative = LIPASR_E*; nothing
