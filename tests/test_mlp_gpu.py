@@ -425,16 +425,16 @@ def test_batchnorm_inside_the_gemm_equals_the_launch_chain(cuda, widths, batch, 
     assert float(b1.sub(b0).abs().max()) <= 1e-6 * float(b0.abs().max())
 
 
-@pytest.mark.parametrize("batch,drop", [(1024, True), (1000, False), (800, True)])
-def test_exchange_tiles_of_128_rows_on_a_cu_share_equal_the_launch_chain(cuda, batch, drop):
+@pytest.mark.parametrize("batch,drop,width1", [(1024, True, 1024), (1000, False, 1024), (800, True, 1024), (1024, True, 1000)])
+def test_exchange_tiles_of_128_rows_on_a_cu_share_equal_the_launch_chain(cuda, batch, drop, width1):
     """Arithmetic mode 2 on a CU share (lipasr_mlp_set_cu_budget(plan, 128), what the pipeline sets beside the extraction stream):
     layer 1's forward GEMM and the input-gradient GEMM into it run on 128 x 64 tiles with the split pass (gemm_ring2_tile), the
     weight gradients on 128 x 128 split-pass tiles.  Same step as the launch chain (GEMM + bn_apply, 64 x 64 tiles) to rounding
     level, bitwise reproducible, no exchange gave up -- and the launch counters say those kernels really ran.  Ragged batches:
-    1000 = 7 full row tiles + 104 rows, 800 = 6 + 32."""
+    1000 = 7 full row tiles + 104 rows, 800 = 6 + 32; a first hidden layer of 1000 units: a ragged last column block (40 of 64 columns)."""
     from lipasr import _native as N
 
-    widths = (880, 1024, 512, 256, 128, 64, 10)
+    widths = (880, width1, 512, 256, 128, 64, 10)
     spec = [P.LayerSpec(widths[i], widths[i + 1], i + 2 < len(widths), (0.1 if (drop and i < 3 and i + 2 < len(widths)) else 0.0), True)
             for i in range(len(widths) - 1)]
     p = _random_state(spec, 4)
