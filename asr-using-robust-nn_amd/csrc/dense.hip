@@ -408,24 +408,44 @@ __device__ __forceinline__ void bn_col_stats(double s1, double s2, int Bstat, fl
 
 // The tile's R rows x 4 columns per thread after the exchange.  val: a (forward) or g (backward); av: post-ReLU a (backward).
 // colp (LDS floats): forward [mean | rstd] per column of the block, backward [dbeta | dgamma].
+// The per-column operands of bnx_finish that do not depend on the exchange (forward gamma / beta, backward gamma and the saved mean /
+// rstd): requested BEFORE the exchange, so that their round trip runs beside its waits instead of behind them
+struct BnxLate {
+  float ga[4], b0[4], b1[4];  // forward: gamma, beta, -; backward: gamma, saved mean, saved rstd
+};
+__device__ __forceinline__ void bnx_late_load(const GemmArgs& g, const int gn, BnxLate& q) {
+  const bool fwd = g.epi == EPI_BIAS_RELU_BNX;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const bool cv = gn + e < g.N;
+    q.ga[e] = cv ? g.gamma[gn + e] : 1.0f;
+    if (fwd) {
+      q.b0[e] = cv ? g.beta[gn + e] : 0.0f;
+      q.b1[e] = 0.0f;
+    } else {
+      q.b0[e] = cv ? g.save_mean[gn + e] : 0.0f;
+      q.b1[e] = cv ? g.save_mean[g.N + gn + e] : 1.0f;
+    }
+  }
+}
+
 template <int R>
 __device__ __forceinline__ void bnx_finish(const GemmArgs& g, const int step, const int* gm, const int gn, const float (*val)[4],
-                                           const float (*av)[4], const float* colp, const int CB, const int c4) {
+                                           const float (*av)[4], const float* colp, const int CB, const int c4, const BnxLate& lt) {
   const bool fwd = g.epi == EPI_BIAS_RELU_BNX;
   float ga[4], p0[4], p1[4], be[4], mean[4], rstd[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    const bool cv = gn + e < g.N;
-    ga[e] = cv ? g.gamma[gn + e] : 1.0f;
+    ga[e] = lt.ga[e];
     p0[e] = colp[c4 + e];
     p1[e] = colp[CB + c4 + e];
     if (fwd) {
-      be[e] = cv ? g.beta[gn + e] : 0.0f;
+      be[e] = lt.b0[e];
       mean[e] = p0[e]; rstd[e] = p1[e];
     } else {
       be[e] = 0.0f;
-      mean[e] = cv ? g.save_mean[gn + e] : 0.0f;
-      rstd[e] = cv ? g.save_mean[g.N + gn + e] : 1.0f;
+      mean[e] = lt.b0[e];
+      rstd[e] = lt.b1[e];
     }
   }
   const float invB = 1.0f / (float)g.Bstat;
@@ -660,6 +680,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
         mine[tid] = t;
       }
       __syncthreads();
+      BnxLate late;
+      bnx_late_load(g, gn, late);
       XcView xc{g.xc_gran, g.xc_ctrl, g.xc_err, g.xc_rt_max};
       xc_exchange<256, 32>(xc, bx, by, g.Bstat < 0 ? 0 : n_row_tiles, xtag, mine, sbuf, tot, [&]() {  // (Bstat < 0: timing probe, below)
         if (g.epi == EPI_BIAS_RELU_BNX && gm1[0] < g.M) {  // the post-ReLU activations: the backward pass reads them
@@ -675,7 +697,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
       });
       if (tid < TS) bnx_column(g, by, n0 + tid, tid, TS, tot, colp);
       __syncthreads();
-      bnx_finish<1>(g, step, gm1, gn, val, av, colp, TS, c4);
+      bnx_finish<1>(g, step, gm1, gn, val, av, colp, TS, c4, late);
       return;
     }
   }
@@ -966,6 +988,8 @@ __device__ __forceinline__ void lds_tile_epilogue(const GemmArgs& g, const f32x1
       mine[tid] = t;
     }
     __syncthreads();
+    BnxLate late;
+    bnx_late_load(g, gn, late);
     XcView xc{g.xc_gran, g.xc_ctrl, g.xc_err, g.xc_rt_max};
     xc_exchange<512, 64>(xc, bx, by, g.Bstat < 0 ? 0 : n_row_tiles, xtag, mine, sbuf, tot, [&]() {
       if (g.epi != EPI_BIAS_RELU_BNX) return;
@@ -984,7 +1008,7 @@ __device__ __forceinline__ void lds_tile_epilogue(const GemmArgs& g, const f32x1
     });
     if (tid < TS) bnx_column(g, by, n0 + tid, tid, TS, tot, colp);
     __syncthreads();
-    bnx_finish<2>(g, step, gm2, gn, val, av, colp, TS, c4);
+    bnx_finish<2>(g, step, gm2, gn, val, av, colp, TS, c4, late);
     return;
   }
   float cs1[4] = {0.f, 0.f, 0.f, 0.f}, cs2[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1829,6 +1853,8 @@ __device__ __forceinline__ void gemm_ring2_tile(const GemmArgs& g, const int bx,
     mine[tid] = t;
   }
   __syncthreads();
+  BnxLate late;
+  bnx_late_load(g, gn, late);
   XcView xc{g.xc_gran, g.xc_ctrl, g.xc_err, g.xc_rt_max};
   xc_exchange<512, 64>(xc, bx, by, g.Bstat < 0 ? 0 : n_row_tiles, xtag, mine, sbuf, tot, [&]() {
     if (g.epi != EPI_BIAS_RELU_BNX) return;
@@ -1847,7 +1873,7 @@ __device__ __forceinline__ void gemm_ring2_tile(const GemmArgs& g, const int bx,
   });
   if (tid < TS) bnx_column(g, by, n0 + tid, tid, TS, tot, colp);
   __syncthreads();
-  bnx_finish<4>(g, step, gm4, gn, val, av, colp, TS, c4);
+  bnx_finish<4>(g, step, gm4, gn, val, av, colp, TS, c4, late);
 }
 
 template <int BMODE>
