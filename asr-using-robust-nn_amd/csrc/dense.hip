@@ -482,16 +482,21 @@ __device__ __forceinline__ void bnx_finish(const GemmArgs& g, const int step, co
 
 // one column of the block after the exchange: forward -> [mean | rstd] (+ moving statistics and the saved statistics, by
 // row tile 0), backward -> [dbeta | dgamma] (+ the parameter gradients, by row tile 0)
+// (mm0, mv0: the column's moving statistics, requested by row tile 0 before the exchange -- bnx_moving_load)
+__device__ __forceinline__ void bnx_moving_load(const GemmArgs& g, const int by, const int col, const bool mine, float& mm0, float& mv0) {
+  mm0 = 0.0f; mv0 = 0.0f;
+  if (mine && g.epi == EPI_BIAS_RELU_BNX && by == 0 && col < g.N) { mm0 = g.mmean_w[col]; mv0 = g.mvar_w[col]; }
+}
 __device__ __forceinline__ void bnx_column(const GemmArgs& g, const int by, const int col, const int j, const int CB, const double* tot,
-                                           float* colp) {
+                                           float* colp, const float mm0, const float mv0) {
   if (g.epi == EPI_BIAS_RELU_BNX) {
     float mean, var, rstd;
     bn_col_stats(tot[j], tot[CB + j], g.Bstat, mean, var, rstd);
     colp[j] = mean;
     colp[CB + j] = rstd;
     if (by == 0 && col < g.N) {
-      g.mmean_w[col] = g.mmean_w[col] * kBnMomentum + mean * (1.0f - kBnMomentum);
-      g.mvar_w[col] = g.mvar_w[col] * kBnMomentum + var * (1.0f - kBnMomentum);
+      g.mmean_w[col] = mm0 * kBnMomentum + mean * (1.0f - kBnMomentum);
+      g.mvar_w[col] = mv0 * kBnMomentum + var * (1.0f - kBnMomentum);
       g.save_w[col] = mean;
       g.save_w[g.N + col] = rstd;
     }
@@ -682,6 +687,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
       __syncthreads();
       BnxLate late;
       bnx_late_load(g, gn, late);
+      float mm0, mv0;
+      bnx_moving_load(g, by, n0 + tid, tid < TS, mm0, mv0);
       XcView xc{g.xc_gran, g.xc_ctrl, g.xc_err, g.xc_rt_max};
       xc_exchange<256, 32>(xc, bx, by, g.Bstat < 0 ? 0 : n_row_tiles, xtag, mine, sbuf, tot, [&]() {  // (Bstat < 0: timing probe, below)
         if (g.epi == EPI_BIAS_RELU_BNX && gm1[0] < g.M) {  // the post-ReLU activations: the backward pass reads them
@@ -695,7 +702,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
           }
         }
       });
-      if (tid < TS) bnx_column(g, by, n0 + tid, tid, TS, tot, colp);
+      if (tid < TS) bnx_column(g, by, n0 + tid, tid, TS, tot, colp, mm0, mv0);
       __syncthreads();
       bnx_finish<1>(g, step, gm1, gn, val, av, colp, TS, c4, late);
       return;
@@ -990,6 +997,8 @@ __device__ __forceinline__ void lds_tile_epilogue(const GemmArgs& g, const f32x1
     __syncthreads();
     BnxLate late;
     bnx_late_load(g, gn, late);
+    float mm0, mv0;
+    bnx_moving_load(g, by, n0 + tid, tid < TS, mm0, mv0);
     XcView xc{g.xc_gran, g.xc_ctrl, g.xc_err, g.xc_rt_max};
     xc_exchange<512, 64>(xc, bx, by, g.Bstat < 0 ? 0 : n_row_tiles, xtag, mine, sbuf, tot, [&]() {
       if (g.epi != EPI_BIAS_RELU_BNX) return;
@@ -1006,7 +1015,7 @@ __device__ __forceinline__ void lds_tile_epilogue(const GemmArgs& g, const f32x1
         }
       }
     });
-    if (tid < TS) bnx_column(g, by, n0 + tid, tid, TS, tot, colp);
+    if (tid < TS) bnx_column(g, by, n0 + tid, tid, TS, tot, colp, mm0, mv0);
     __syncthreads();
     bnx_finish<2>(g, step, gm2, gn, val, av, colp, TS, c4, late);
     return;
@@ -1855,6 +1864,8 @@ __device__ __forceinline__ void gemm_ring2_tile(const GemmArgs& g, const int bx,
   __syncthreads();
   BnxLate late;
   bnx_late_load(g, gn, late);
+  float mm0, mv0;
+  bnx_moving_load(g, by, n0 + tid, tid < TS, mm0, mv0);
   XcView xc{g.xc_gran, g.xc_ctrl, g.xc_err, g.xc_rt_max};
   xc_exchange<512, 64>(xc, bx, by, g.Bstat < 0 ? 0 : n_row_tiles, xtag, mine, sbuf, tot, [&]() {
     if (g.epi != EPI_BIAS_RELU_BNX) return;
@@ -1871,7 +1882,7 @@ __device__ __forceinline__ void gemm_ring2_tile(const GemmArgs& g, const int bx,
       }
     }
   });
-  if (tid < TS) bnx_column(g, by, n0 + tid, tid, TS, tot, colp);
+  if (tid < TS) bnx_column(g, by, n0 + tid, tid, TS, tot, colp, mm0, mv0);
   __syncthreads();
   bnx_finish<4>(g, step, gm4, gn, val, av, colp, TS, c4, late);
 }
