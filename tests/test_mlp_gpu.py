@@ -477,6 +477,38 @@ def test_exchange_tiles_of_128_rows_on_a_cu_share_equal_the_launch_chain(cuda, b
     assert float(b1.sub(b0).abs().max()) <= 1e-5 * float(b0.abs().max())
 
 
+def test_first_step_of_a_fresh_process_takes_the_exchange_tiles(cuda):
+    """The exchange instances are chosen by an occupancy query that used to run BEFORE their first launch had raised the kernel's
+    dynamic-LDS limit: the runtime answered 0, the answer was cached, and a fresh process trained through the launch chain until
+    something else had launched those kernels (the tests above passed in this file and failed in the full suite).  One mode-2 step
+    on a 128-CU budget in a NEW interpreter: both large layer-1 GEMMs on 128 x 64 exchange tiles, the weight gradients on split-pass
+    tiles, no exchange error."""
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = (
+        "import sys, numpy as np, torch\n"
+        f"sys.path[:0] = [{here!r}, {os.path.join(os.path.dirname(here), 'asr-using-robust-nn_amd')!r}, {os.path.dirname(here)!r}]\n"
+        "from helpers import build_model, dev, load_params\n"
+        "from oracle import mlp_ref as P\n"
+        "from lipasr import _native as N\n"
+        "w = (880, 1024, 512, 256, 128, 64, 10)\n"
+        "spec = [P.LayerSpec(w[i], w[i + 1], i + 2 < len(w), 0.0, True) for i in range(len(w) - 1)]\n"
+        "p = P.init_params(spec, seed=1, dtype=np.float32, nonneg_init=True)\n"
+        "rng = np.random.default_rng(0)\n"
+        "x = dev(rng.standard_normal((1024, 880)).astype(np.float32)); y = dev(P.to_categorical(rng.integers(0, 10, 1024), 10))\n"
+        "m = build_model(spec, max_batch=1024, compute_dtype='float16x2'); load_params(m, p)\n"
+        "N.check(N.lib.lipasr_mlp_set_cu_budget(m._plan, 128)); N.check(N.lib.lipasr_mlp_set_gemm_tiles(m._plan, 128))\n"
+        "m.train_fwd_bwd(x, y); torch.cuda.synchronize()\n"
+        "print('COUNTS', N.lib.lipasr_debug_launch_count(0), N.lib.lipasr_debug_launch_count(1), m.exchange_errors())\n"
+    )
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("COUNTS")][-1].split()
+    assert line[1:] == ["2", "1", "0"], out.stdout
+
+
 def test_batchnorm_inside_the_gemm_over_thirty_steps(cuda):
     """VERDICT r4 item 1's bar for a restructured step: parameters within 1e-6 (of the largest weight) of the launch-chain path
     after 30 training steps with the constraint, dropout on."""
