@@ -215,6 +215,15 @@ def run_config(opt, pool, batch, rank, world, device, steps, warmup, profile):
         else:
             pipe.step(waves[s:s + batch], y[s:s + batch])
 
+    prewarm_ms = float(os.environ.get("LIPASR_BENCH_PREWARM_MS", "0"))
+    if prewarm_ms > 0:  # A/B probe (not a default): is the slowness of the first timed steps the device's clock ramp?
+        a = torch.randn(4096, 4096, device=device)
+        tw = time.perf_counter()
+        while (time.perf_counter() - tw) * 1e3 < prewarm_ms:
+            for _ in range(8):
+                a = (a @ a).clamp_(-1.0, 1.0)
+            torch.cuda.synchronize()
+        del a
     for i in range(warmup):
         one(i)
     pipe.synchronize()
