@@ -1361,6 +1361,16 @@ __global__ __launch_bounds__(512 + 64 * kRingLoaders) void gemm_ring_kernel(Gemm
   if (g.xcd_map) xcd_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x, gridDim.y, bx, by);
   gemm_ring_tile<AMODE, BMODE, X, kRingLoaders>(g, bx, by, gridDim.y);
 }
+// The exchange instance for launches of at most ONE workgroup per CU (layer 2 on a 128-CU share, layer 1 on the whole chip): four loader
+// wavefronts.  Same box, interleaved, loaders on every exchange launch: config 2 0.3067 against 0.3098 ms (its 256-tile launches are one per
+// CU); config 3 lost (two workgroups of twelve wavefronts no longer share a CU at 81 registers) -- hence per launch.
+constexpr int kRingLoadersOnePerCu = 4;
+template <int BMODE>
+__global__ __launch_bounds__(512 + 64 * kRingLoadersOnePerCu) void gemm_ring_x1_kernel(GemmArgs g) {
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (g.xcd_map) xcd_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x, gridDim.y, bx, by);
+  gemm_ring_tile<0, BMODE, true, kRingLoadersOnePerCu>(g, bx, by, gridDim.y);
+}
 
 template <int AMODE, int BMODE, int BF = 0, int BK = kLdsBKMax, bool X = false>
 __global__ __launch_bounds__(512) void gemm_lds_kernel(GemmArgs g) {
@@ -1911,6 +1921,7 @@ static bool ring_legal(int amode, int bmode, const GemmArgs& g) {
 // plan's share: then it halves the workgroups and moves 3/4 of the bytes per CU; with fewer tiles than that it would leave CUs idle.
 // One workgroup per CU (124 KB of LDS) and every workgroup resident (the exchange): at most `cus` tiles.
 static int g_ring2 = 1;  // lipasr_debug_gemm_mode bit 8 clears it (A/B knob)
+static int g_ring_x1 = 1;  // bit 9 clears it: no loader-wavefront instance for exchange launches of one workgroup per CU
 static long g_launch_count[2] = {0, 0};  // lipasr_debug_launch_count: 0 = launches on 128 x 64 exchange tiles, 1 = weight-gradient launches with 128 x 128 split-pass tiles
 static bool use_ring2(int bmode, const GemmArgs& g) {
   if (!g_ring2 || g.bf16 != 2 || g.M < 128 || g.N < 64 || !ring_legal(0, bmode, g)) return false;
@@ -2084,9 +2095,16 @@ static int launch_gemm(int amode, int bmode, const GemmArgs& g, hipStream_t st) 
       if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring_kernel<0, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_gemm_bytes());
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring_kernel<0, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_gemm_bytes());
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring_x1_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_gemm_bytes());
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring_x1_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_gemm_bytes());
         attr_set = true;
       }
-      if (bmode == 0) hipLaunchKernelGGL((gemm_ring_kernel<0, 0, true>), grid, dim3(512 + 64 * kRingLoaders), ring_gemm_bytes(), st, g);
+      int cus = g.cus;
+      if (cus <= 0) { hipDeviceProp_t prop; int dev = 0; (void)hipGetDevice(&dev); cus = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256; }
+      if (g_ring_x1 && (long)grid.x * grid.y <= (long)cus) {  // at most one workgroup per CU: the instance with loader wavefronts
+        if (bmode == 0) hipLaunchKernelGGL((gemm_ring_x1_kernel<0>), grid, dim3(512 + 64 * kRingLoadersOnePerCu), ring_gemm_bytes(), st, g);
+        else hipLaunchKernelGGL((gemm_ring_x1_kernel<1>), grid, dim3(512 + 64 * kRingLoadersOnePerCu), ring_gemm_bytes(), st, g);
+      } else if (bmode == 0) hipLaunchKernelGGL((gemm_ring_kernel<0, 0, true>), grid, dim3(512 + 64 * kRingLoaders), ring_gemm_bytes(), st, g);
       else hipLaunchKernelGGL((gemm_ring_kernel<0, 1, true>), grid, dim3(512 + 64 * kRingLoaders), ring_gemm_bytes(), st, g);
     } else if (use_lds_gemm(g.M, g.N, g.K, g.lds_min_tiles)) {
       const dim3 grid((g.N + 63) / 64, (g.M + 63) / 64);
@@ -2591,13 +2609,14 @@ extern "C" {
 long lipasr_debug_launch_count(int kind) { return (kind == 0 || kind == 1) ? g_launch_count[kind] : -1; }
 
 int lipasr_debug_gemm_mode(int mode) {
-  g_gemm_mode = mode & 3;  // (bits: 0-1 kernel choice, 2 split dW_0, 3 grouped launch on fragment tiles, 4 XCD-aware tile map, 5 no LDS-DMA ring, 6 64 x 64 ring tile for the weight gradients, 7 the 128 x 128 tile without the split pass, 8 no 128 x 64 exchange tiles)
+  g_gemm_mode = mode & 3;  // (bits: 0-1 kernel choice, 2 split dW_0, 3 grouped launch on fragment tiles, 4 XCD-aware tile map, 5 no LDS-DMA ring, 6 64 x 64 ring tile for the weight gradients, 7 the 128 x 128 tile without the split pass, 8 no 128 x 64 exchange tiles, 9 no loader instance of the 64 x 64 exchange ring tile)
   g_split_dw0 = (mode >> 2) & 1;
   g_group_lds = ((mode >> 3) & 1) ? 0 : 1;
   g_xcd_map = (mode >> 4) & 1;
   g_no_ring = (mode >> 5) & 1;
   g_ring_tile = ((mode >> 6) & 1) ? 1 : ((mode >> 7) & 1) ? 3 : 2;
   g_ring2 = ((mode >> 8) & 1) ? 0 : 1;
+  g_ring_x1 = ((mode >> 9) & 1) ? 0 : 1;
   return LIPASR_OK;
 }
 

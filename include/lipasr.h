@@ -457,7 +457,8 @@ int lipasr_debug_set(lipasr_handle_t h, int key, int value);
  * (as the data-parallel head / dw0 pair does) instead of inside the grouped launch.  bit 3 (8): the grouped weight-gradient
  * launch on 32x32 register-fragment tiles (round 2) instead of 64x64 LDS tiles.  Round 5 (arithmetic mode 2 only): bit 4 (16) the
  * XCD-aware tile order, bit 5 (32) no LDS-DMA ring kernels, bit 6 (64) the weight gradients on 64x64 ring tiles, bit 7 (128) on
- * 128x128 tiles that split per fragment (no split pass), bit 8 (256) no 128x64 exchange tiles.  Same results in every setting. */
+ * 128x128 tiles that split per fragment (no split pass), bit 8 (256) no 128x64 exchange tiles, bit 9 (512) no loader-wavefront instance of the 64x64 exchange tile.  Same results in
+ * every setting (to the rounding of a different summation order where the tile changes). */
 int lipasr_debug_gemm_mode(int mode);
 
 /* Test hook: how many launches since the library was loaded took kernel family `kind` -- 0: forward / input-gradient GEMMs on
