@@ -26,7 +26,10 @@ constexpr int kMaxR = 32;
 constexpr int kMaxOrder = 64;
 constexpr int kChainRowsPerWave = 1;
 constexpr int kChainRowsPerBlock = 4 * kChainRowsPerWave;
-constexpr int kSquarings = 40;
+#ifndef LIPASR_SQUARINGS
+#define LIPASR_SQUARINGS 40
+#endif
+constexpr int kSquarings = LIPASR_SQUARINGS;
 #ifndef LIPASR_SIGMA_WGS
 #define LIPASR_SIGMA_WGS 256  // workgroups of sigma_scale_layers_kernel (each recomputes sigma, then scales its slice of a layer)
 #endif
