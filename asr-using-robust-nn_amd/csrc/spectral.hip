@@ -31,7 +31,7 @@ constexpr int kChainRowsPerBlock = 4 * kChainRowsPerWave;
 #endif
 constexpr int kSquarings = LIPASR_SQUARINGS;
 #ifndef LIPASR_SIGMA_WGS
-#define LIPASR_SIGMA_WGS 256  // workgroups of sigma_scale_layers_kernel (each recomputes sigma, then scales its slice of a layer)
+#define LIPASR_SIGMA_WGS 192  // workgroups of sigma_scale_layers_kernel (each recomputes sigma, then scales its slice of a layer)
 #endif
 
 // ---------------------------------------------------------------------------------------------
@@ -444,7 +444,11 @@ __global__ __launch_bounds__(256) void scale_layers_kernel(LayerPtrs lp, const f
 // so all of them apply the same factors.  Replaces product_sigma_kernel (14 us: one workgroup summing 220 cross-XCD Gram
 // partials) + a launch boundary + scale_layers_kernel (8 us) on the critical path of every training step; the chain's last
 // step no longer emits Gram partials for it.  Workgroup (0, 0) also writes scales / norms / sigma and bumps the step counter.
-__global__ __launch_bounds__(256) void sigma_scale_layers_kernel(const float* __restrict__ P, int n, int R, double rho, OrderArgs oa,
+#ifndef LIPASR_SSL_THREADS
+#define LIPASR_SSL_THREADS 512
+#endif
+constexpr int kSslThreads = LIPASR_SSL_THREADS, kSslWaves = kSslThreads / 64;  // 256 / 512 / 1024 threads: 22.8 / 20.6 / 29.6 us (the Gram of the product, 4.8 us with four wavefronts, gets faster, everything behind a barrier slower)
+__global__ __launch_bounds__(kSslThreads) void sigma_scale_layers_kernel(const float* __restrict__ P, int n, int R, double rho, OrderArgs oa,
                                                                   LayerPtrs lp, float* __restrict__ scales_out, float* __restrict__ norms_out,
                                                                   float* __restrict__ sigma_out, int* __restrict__ bump) {
   extern __shared__ __attribute__((aligned(16))) char ssl_raw[];
@@ -453,15 +457,15 @@ __global__ __launch_bounds__(256) void sigma_scale_layers_kernel(const float* __
   // dynamic LDS: A | B | four Gram partials (doubles, R^2 each) | P [R][n] floats: 40 kB for 10 x 880, four workgroups per CU
   double* A = reinterpret_cast<double*>(ssl_raw);
   double* B = A + RR;
-  double* gpart0 = B + RR;  // [4][RR]
-  float* Ps = reinterpret_cast<float*>(gpart0 + 4 * RR);
+  double* gpart0 = B + RR;  // [kSslWaves][RR]
+  float* Ps = reinterpret_cast<float*>(gpart0 + kSslWaves * RR);
   __shared__ float sc_s[LIPASR_MAX_LAYERS];
   if ((total & 3) == 0 && (reinterpret_cast<uintptr_t>(P) & 15) == 0) {
     const float4* src = reinterpret_cast<const float4*>(P);
     float4* dst = reinterpret_cast<float4*>(Ps);
-    for (int f = tid; f < (total >> 2); f += 256) dst[f] = src[f];
+    for (int f = tid; f < (total >> 2); f += kSslThreads) dst[f] = src[f];
   } else {
-    for (int f = tid; f < total; f += 256) Ps[f] = P[f];
+    for (int f = tid; f < total; f += kSslThreads) Ps[f] = P[f];
   }
   __syncthreads();
   // Gram (symmetric: the R (R + 1) / 2 entries a <= b): wavefront w takes the column quads q = w (mod 4), lane e (and e + 64, ...)
@@ -477,20 +481,29 @@ __global__ __launch_bounds__(256) void sigma_scale_layers_kernel(const float* __
       const float* pb = Ps + (size_t)b * n;
       double s = 0.0;
       if ((n & 3) == 0) {
-        for (int q = w; q < nq; q += 4) {
+        for (int q = w; q < nq; q += kSslWaves) {
           const float4 x = *reinterpret_cast<const float4*>(pa + 4 * q), y = *reinterpret_cast<const float4*>(pb + 4 * q);
           s = fma((double)x.x, (double)y.x, s); s = fma((double)x.y, (double)y.y, s);
           s = fma((double)x.z, (double)y.z, s); s = fma((double)x.w, (double)y.w, s);
         }
       } else {
-        for (int i = w; i < n; i += 4) s = fma((double)pa[i], (double)pb[i], s);
+        for (int i = w; i < n; i += kSslWaves) s = fma((double)pa[i], (double)pb[i], s);
       }
       gpart0[w * RR + a * R + b] = s;
       gpart0[w * RR + b * R + a] = s;
     }
   }
   __syncthreads();
-  for (int e = tid; e < RR; e += 256) A[e] = (gpart0[e] + gpart0[RR + e]) + (gpart0[2 * RR + e] + gpart0[3 * RR + e]);
+  for (int e = tid; e < RR; e += kSslThreads) {  // (fixed order: a pairwise tree over the wavefronts' partial sums)
+    double part[kSslWaves];
+#pragma unroll
+    for (int w = 0; w < kSslWaves; ++w) part[w] = gpart0[w * RR + e];
+#pragma unroll
+    for (int h = kSslWaves / 2; h >= 1; h >>= 1)
+#pragma unroll
+      for (int w = 0; w < h; ++w) part[w] = part[2 * w] + part[2 * w + 1];
+    A[e] = part[0];
+  }
   __syncthreads();
   double t0 = 0.0;
   for (int a = 0; a < R; ++a) t0 += A[a * R + a];
@@ -500,7 +513,7 @@ __global__ __launch_bounds__(256) void sigma_scale_layers_kernel(const float* __
   const bool zero = !(t0 > 0.0);
   int n_it = 0;
   if (!zero) {
-    for (int e = tid; e < RR; e += 256) A[e] /= t0;
+    for (int e = tid; e < RR; e += kSslThreads) A[e] /= t0;
     __syncthreads();
     // A <- A^2 / tr(A^2).  The traces are kept and their logarithms taken AFTER the loop, all at once (one fp64 log per
     // squaring inside the loop was a serial chain of ~150 dependent instructions in every workgroup: 6 of the kernel's 22 us)
@@ -511,7 +524,7 @@ __global__ __launch_bounds__(256) void sigma_scale_layers_kernel(const float* __
     double* nxt = B;
     double c2 = 1.0;
     for (int it = 0; it < kSquarings; ++it) {
-      for (int e = tid; e < RR; e += 256) {
+      for (int e = tid; e < RR; e += kSslThreads) {
         const int a = e / R, b = e - a * R;
         double s = 0.0;
         for (int c = 0; c < R; ++c) s = fma(cur[a * R + c], cur[c * R + b], s);
@@ -565,18 +578,18 @@ __global__ __launch_bounds__(256) void sigma_scale_layers_kernel(const float* __
   float* w = lp.W[l];
   const size_t nw = (size_t)lp.rows[l] * lp.cols[l];
   const size_t j = (size_t)((int)blockIdx.x - lp.wg_start[l]);
-  const size_t stride = (size_t)(lp.wg_start[l + 1] - lp.wg_start[l]) * 256;
+  const size_t stride = (size_t)(lp.wg_start[l + 1] - lp.wg_start[l]) * kSslThreads;
   if ((reinterpret_cast<uintptr_t>(w) & 15) == 0) {
     const size_t n4 = nw >> 2;
     float4* w4 = reinterpret_cast<float4*>(w);
-    for (size_t i = j * 256 + threadIdx.x; i < n4; i += stride) {
+    for (size_t i = j * kSslThreads + threadIdx.x; i < n4; i += stride) {
       float4 x = w4[i];
       x.x *= s; x.y *= s; x.z *= s; x.w *= s;
       w4[i] = x;
     }
-    for (size_t i = (n4 << 2) + j * 256 + threadIdx.x; i < nw; i += stride) w[i] *= s;
+    for (size_t i = (n4 << 2) + j * kSslThreads + threadIdx.x; i < nw; i += stride) w[i] *= s;
   } else {
-    for (size_t i = j * 256 + threadIdx.x; i < nw; i += stride) w[i] *= s;
+    for (size_t i = j * kSslThreads + threadIdx.x; i < nw; i += stride) w[i] *= s;
   }
 }
 
@@ -1203,7 +1216,7 @@ int lipasr::project_product_bump(lipasr_handle_t h, float* const* Ws, const int*
   ChainScratch cs;
   int n_part = 0;
   const int R = cols[n_layers - 1], n0 = rows[0];
-  const size_t lds = (size_t)6 * R * R * sizeof(double) + (size_t)R * n0 * sizeof(float) + 16;
+  const size_t lds = (size_t)(2 + kSslWaves) * R * R * sizeof(double) + (size_t)R * n0 * sizeof(float) + 16;
   if (n_order > 0 && lds <= 96 * 1024) {
     // the step's critical path: chain -> ONE launch that finds sigma and rescales (every workgroup for itself)
     const float* p_final = nullptr;
@@ -1231,7 +1244,7 @@ int lipasr::project_product_bump(lipasr_handle_t h, float* const* Ws, const int*
       }
       lp.wg_start[n_layers] = acc_wg;
     }
-    hipLaunchKernelGGL(sigma_scale_layers_kernel, dim3(lp.wg_start[n_layers]), dim3(256), lds, S(stream), p_final, n0, R, (double)rho, oa, lp, cs.scales,
+    hipLaunchKernelGGL(sigma_scale_layers_kernel, dim3(lp.wg_start[n_layers]), dim3(kSslThreads), lds, S(stream), p_final, n0, R, (double)rho, oa, lp, cs.scales,
                        norms_out, cs.sigma, bump);
     LP_LAUNCH_CHECK();
     return LIPASR_OK;
