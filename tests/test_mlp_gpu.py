@@ -503,7 +503,8 @@ def test_first_step_of_a_fresh_process_takes_the_exchange_tiles(cuda):
         "m.train_fwd_bwd(x, y); torch.cuda.synchronize()\n"
         "print('COUNTS', N.lib.lipasr_debug_launch_count(0), N.lib.lipasr_debug_launch_count(1), m.exchange_errors())\n"
     )
-    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    env = {k: v for k, v in os.environ.items() if k not in ("LIPASR_FUSE_BN", "LIPASR_GEMM_MODE", "LIPASR_GEMM_TILES")}  # (A/B knobs that change the tile choice)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("COUNTS")][-1].split()
     assert line[1:] == ["2", "1", "0"], out.stdout
